@@ -1,0 +1,199 @@
+/* rtc_api.h -- C ABI of librtc_hip.so, the MI355X trace loop behind
+ * gbordelon/ray_tracer_challenge's `render(camera, world) -> canvas`.
+ *
+ * The reference is pure Python and has no FFI of its own; the functions below are what a
+ * binding for its hot path -- render / render_multi (renderer.py:753-835) and everything they
+ * call per pixel (ray_for_pixel :715-751, color_at :562-611, intersect_world :67-79,
+ * prepare_computations :98-244, shade_hit :408-526, lighting :990-1090, is_shadowed :528-560,
+ * reflected_color :355-406, refracted_color :285-353, schlick :246-283, and the per-ray parts
+ * of shapes.py) -- has to call.  INTEGRATION.md shows the ctypes stub for the reference side.
+ *
+ * Conventions: plain pointers and sizes only; every function returns 0 or a negative
+ * rtc_status and leaves a message for rtc_last_error() (thread-local); nothing throws or exits
+ * across the ABI; output buffers are caller-allocated and written only on success.
+ * All scene inputs are fp64 (the reference's dtype); the library keeps fp64 and fp32 device
+ * copies.  A scene handle is immutable after creation and belongs to one GPU.
+ */
+#ifndef RTC_API_H
+#define RTC_API_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RTC_VERSION 100
+
+typedef enum {
+    RTC_OK = 0,
+    RTC_ERR_INVALID = -1,   /* bad argument / inconsistent scene description */
+    RTC_ERR_NO_DEVICE = -2, /* no usable GPU, or device index out of range */
+    RTC_ERR_HIP = -3,       /* a HIP runtime call failed (message has the HIP error string) */
+    RTC_ERR_LIMIT = -4,     /* scene exceeds a compiled-in limit (CSG hits, pattern stack, BVH depth) */
+    RTC_ERR_UNSUPPORTED = -5
+} rtc_status;
+
+/* primitive kinds (shapes.py class -> code) */
+enum { RTC_SPHERE = 0, RTC_PLANE = 1, RTC_CUBE = 2, RTC_CYLINDER = 3, RTC_CONE = 4,
+       RTC_TRIANGLE = 5, RTC_CSG_ROOT = 8 };
+/* CSG operations (shapes.py:409-422) */
+enum { RTC_CSG_UNION = 0, RTC_CSG_INTERSECT = 1, RTC_CSG_DIFFERENCE = 2 };
+/* pattern node types (shapes.py:1501-2033) */
+enum { RTC_PAT_TEST = 0, RTC_PAT_CHECKERS = 1, RTC_PAT_GRADIENT = 2, RTC_PAT_RADIAL = 3,
+       RTC_PAT_RING = 4, RTC_PAT_STRIPE = 5,
+       RTC_PAT_MAP_PLANAR = 9, RTC_PAT_MAP_SPHERICAL = 10, RTC_PAT_MAP_CYLINDRICAL = 11,
+       RTC_PAT_MAP_CUBE = 12, RTC_UV_CHECKER = 20, RTC_UV_ALIGN = 21, RTC_UV_IMAGE = 22 };
+/* pattern program opcodes: a material's pattern is a postfix program over a colour stack.
+ * EVAL pushes node(point); EVAL_AB pops b then a and pushes node(point) evaluated with those
+ * two colours (NestedPattern, shapes.py:1892-1895); BLEND pops two and pushes their mean
+ * (BlendedPattern, shapes.py:1874-1877). */
+enum { RTC_OP_EVAL = 0, RTC_OP_EVAL_AB = 1, RTC_OP_BLEND = 2 };
+
+/* A "prim code" names something a ray can be tested against:
+ *   bits 31..28 kind, bit 27 = does NOT cast shadows, bits 26..0 index
+ * index = leaf id for the analytic kinds, triangle-table row for RTC_TRIANGLE,
+ * CSG-root row for RTC_CSG_ROOT. */
+#define RTC_PRIM(kind, noshadow, index) \
+    ((int32_t)(((uint32_t)(kind) << 28) | ((uint32_t)((noshadow) ? 1u : 0u) << 27) | ((uint32_t)(index) & 0x07FFFFFFu)))
+
+/* Flattened scene, as ray_tracer_challenge_amd.compile emits it.  3x4 matrices are the top
+ * three rows of the reference's 4x4s, row-major.  "leaf" = one primitive shape object, numbered
+ * in depth-first order of world.contains (the id reported in hit-id maps). */
+typedef struct {
+    /* leaves: Shape objects (shapes.py:228-313, 516-887) */
+    int32_t n_leaves;
+    const int32_t *leaf_kind;      /* [n_leaves] */
+    const int32_t *leaf_xform;     /* [n_leaves] row of `xform` */
+    const int32_t *leaf_material;  /* [n_leaves] row of `mat` */
+    const int32_t *leaf_tri;       /* [n_leaves] row of the triangle tables or -1 */
+    const double *leaf_minmax;     /* [n_leaves][2] Cylinder/Cone minimum, maximum */
+    const int32_t *leaf_closed;    /* [n_leaves] */
+    /* collapsed world->object transforms: inverse(T_leaf) * ... * inverse(T_root)
+     * (Shape.intersect shapes.py:271-273 applied down the parent chain; world_to_object :282-286;
+     * its transpose is normal_to_world :288-296) */
+    int32_t n_xforms;
+    const double *xform;           /* [n_xforms][12] */
+    /* triangles, pre-transformed to WORLD space (Triangle/SmoothTriangle shapes.py:799-887) */
+    int32_t n_tris;
+    const double *tri_geom;        /* [n_tris][12] p1, e1, e2, det_eps = EPSILON*|det(object->world)|, 0, 0 */
+    const double *tri_norm;        /* [n_tris][12] world-space (unnormalised) n1, n2, n3, 0,0,0; flat triangles repeat their face normal */
+    const int32_t *tri_leaf;       /* [n_tris] leaf id */
+    /* things rays are tested against */
+    int32_t n_items;               /* bounded: the library builds its AABB BVH over these */
+    const int32_t *item_prim;      /* [n_items] prim codes */
+    const double *item_lo, *item_hi; /* [n_items][3] world-space AABBs */
+    int32_t n_unbounded;           /* planes, uncapped cylinders/cones, CSG with such children: tested for every ray */
+    const int32_t *unbounded_prim;
+    /* CSG (shapes.py:316-422): every top-most CSG object is a "root"; its nodes are stored
+     * children-before-parents; leaves of any subtree are contiguous in leaf order */
+    int32_t n_csg_roots;
+    const int32_t *csg_root;       /* [n][4] first node, node count, first leaf, end leaf */
+    int32_t n_csg_nodes;
+    const int32_t *csg_node;       /* [n][5] op, first leaf, first right leaf, end leaf, xform row (world->csg local) */
+    const double *csg_bbox;        /* [n][6] CSG.bounds() in csg-local space: min xyz, max xyz */
+    /* materials (shapes.py:137-150) */
+    int32_t n_materials;
+    const double *mat;             /* [n][10] color rgb, ambient, diffuse, specular, shininess, reflective, transparency, refractive_index */
+    const int32_t *mat_shadow;     /* [n] casts_shadow */
+    const int32_t *mat_program;    /* [n] row of prog_* or -1 for plain colour */
+    /* pattern nodes and programs */
+    int32_t n_pat_nodes;
+    const int32_t *pat_type;       /* [n] */
+    const double *pat_inv;         /* [n][12] inverse(pattern.transform) */
+    const double *pat_ab;          /* [n][6] colours a, b */
+    const int32_t *pat_child;      /* [n][6] uv-pattern nodes of the map types (cube: right,left,up,down,front,back; cylinder: body,cap) */
+    const double *pat_param;       /* [n][4] uv checker: width, height */
+    const double *pat_colors;      /* [n][15] align check: main, ul, ur, bl, br */
+    const int32_t *pat_tex;        /* [n] texture row or -1 */
+    int32_t n_programs;
+    const int32_t *prog_off;       /* [n] first instruction */
+    const int32_t *prog_len;       /* [n] */
+    int32_t n_instr;
+    const int32_t *instr;          /* [n][2] opcode, pattern node */
+    /* image textures (canvas.py:40-55): RGB8, row-major, rows top to bottom */
+    int32_t n_textures;
+    const int64_t *tex_off;        /* [n] byte offset into tex_data */
+    const int32_t *tex_w, *tex_h;  /* [n] */
+    const double *tex_scale;       /* [n] the image's largest channel value */
+    int64_t tex_bytes;
+    const uint8_t *tex_data;
+    /* lights (renderer.py:895-973) */
+    int32_t n_lights;
+    const int32_t *light_type;     /* [n] 0 point, 1 area */
+    const double *light_geom;      /* [n][9] position | corner, per-step uvec, per-step vvec */
+    const int32_t *light_steps;    /* [n][3] usteps, vsteps, jitter */
+    const double *light_intensity; /* [n][3] */
+} rtc_scene_desc;
+
+/* Camera (renderer.py:667-692) with its transform already inverted (ray_for_pixel :747-748). */
+typedef struct {
+    int32_t hsize, vsize;
+    double half_width, half_height, pixel_size;
+    double inv_transform[12];
+} rtc_camera;
+
+typedef struct {
+    int32_t precision;   /* 64 = fp64 (reference arithmetic), 32 = fp32 throughput mode */
+    int32_t max_depth;   /* the reference's `remaining`, default 5 (renderer.py:562) */
+    int32_t tile_size;   /* pixels per tile edge for rtc_render_tiles*; multiple of 8; 0 -> 32 */
+    int32_t reserved;
+    double shade_eps;    /* over/under-point offset; <= 0 -> 1e-6 in fp64 (renderer.py:15, :221-222), 2e-4 in fp32 */
+    uint64_t seed;       /* jittered area lights only */
+} rtc_render_opts;
+
+typedef struct {
+    int64_t rays[4];     /* traced: primary, shadow, reflection, refraction */
+    double kernel_ms;    /* trace kernel time measured with HIP events on its stream (host-buffer calls only) */
+} rtc_stats;
+
+typedef struct {
+    int32_t device;
+    int32_t bvh_nodes, bvh_depth, bvh_max_leaf;
+    int64_t device_bytes_fp64, device_bytes_fp32;
+} rtc_scene_info;
+
+typedef struct rtc_scene rtc_scene;
+
+int rtc_version(void);
+/* number of visible GPUs (0 on a machine without one); never fails */
+int rtc_device_count(void);
+const char *rtc_last_error(void);
+
+/* Validates `desc`, builds the BVH over its items on the host, uploads fp64 + fp32 copies to
+ * GPU `device`.  The caller keeps ownership of every array in `desc`. */
+int rtc_scene_create(const rtc_scene_desc *desc, int device, rtc_scene **out);
+void rtc_scene_destroy(rtc_scene *scene);
+int rtc_scene_get_info(const rtc_scene *scene, rtc_scene_info *out);
+
+/* render(cam, world) (renderer.py:753-775).  rgb_out: hsize*vsize*3 doubles in the reference's
+ * canvas order [x][y][c] (canvas.py:60); hit_id_out: hsize*vsize leaf ids of the primary hit,
+ * -1 = miss, or NULL; stats_out may be NULL.  Host buffers; synchronous. */
+int rtc_render(rtc_scene *scene, const rtc_camera *cam, const rtc_render_opts *opts,
+               double *rgb_out, int32_t *hit_id_out, rtc_stats *stats_out);
+
+/* render_multi's unit of work (renderer.py:781-793, 811-817): only the listed tiles.  Tiles are
+ * tile_size x tile_size pixels, numbered row-major over the image (tile = ty * tiles_x + tx).
+ * Output is COMPACT: slot k of rgb_out/hit_id_out holds tile tile_ids[k] as [ty][tx] rows of
+ * tile_size pixels (pixels outside the image are left untouched).  Host buffers; synchronous. */
+int rtc_render_tiles(rtc_scene *scene, const rtc_camera *cam, const rtc_render_opts *opts,
+                     int32_t n_tiles, const int32_t *tile_ids,
+                     double *rgb_out, int32_t *hit_id_out, rtc_stats *stats_out);
+
+/* Device-pointer form for callers that keep the frame in HBM (bench.py, the multi-GPU gather).
+ * tile_ids_dev == NULL renders the whole frame into the [x][y][c] layout; otherwise the
+ * compact tile layout above.  rays_dev ([4] int64, may be NULL) is ADDED to.  Asynchronous on
+ * `stream` (a hipStream_t, NULL = default stream). */
+int rtc_render_device(rtc_scene *scene, const rtc_camera *cam, const rtc_render_opts *opts,
+                      int32_t n_tiles, const int32_t *tile_ids_dev,
+                      double *rgb_dev, int32_t *hit_id_dev, int64_t *rays_dev, void *stream);
+
+/* construct_ppm_body (canvas.py:133-156) on the device: [x][y][c] fp64 -> [y][x][c] bytes.
+ * max_component is 1.0 for default_clamping True, else the canvas maximum (the caller
+ * computes it, e.g. with a device-side max over rgb_dev). */
+int rtc_quantize_device(const double *rgb_dev, int32_t hsize, int32_t vsize, double max_component,
+                        uint8_t *out_dev, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,231 @@
+"""ctypes binding of `include/rtc_api.h` (librtc_hip.so).  No CPU fallback: if the library is
+missing, or there is no GPU, every entry point here raises."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librtc_hip.so")
+_lib = None
+_P = C.c_void_p
+
+# (field name, kind) in the exact order of rtc_scene_desc; kind 'n' = int32 count,
+# 'n64' = int64 count, 'p' = pointer to the array of the same name in CompiledScene.arrays
+_DESC_FIELDS = [
+    ("n_leaves", "n"), ("leaf_kind", "p"), ("leaf_xform", "p"), ("leaf_material", "p"), ("leaf_tri", "p"),
+    ("leaf_minmax", "p"), ("leaf_closed", "p"),
+    ("n_xforms", "n"), ("xform", "p"),
+    ("n_tris", "n"), ("tri_geom", "p"), ("tri_norm", "p"), ("tri_leaf", "p"),
+    ("n_items", "n"), ("item_prim", "p"), ("item_lo", "p"), ("item_hi", "p"),
+    ("n_unbounded", "n"), ("unbounded_prim", "p"),
+    ("n_csg_roots", "n"), ("csg_root", "p"), ("n_csg_nodes", "n"), ("csg_node", "p"), ("csg_bbox", "p"),
+    ("n_materials", "n"), ("mat", "p"), ("mat_shadow", "p"), ("mat_program", "p"),
+    ("n_pat_nodes", "n"), ("pat_type", "p"), ("pat_inv", "p"), ("pat_ab", "p"), ("pat_child", "p"),
+    ("pat_param", "p"), ("pat_colors", "p"), ("pat_tex", "p"),
+    ("n_programs", "n"), ("prog_off", "p"), ("prog_len", "p"), ("n_instr", "n"), ("instr", "p"),
+    ("n_textures", "n"), ("tex_off", "p"), ("tex_w", "p"), ("tex_h", "p"), ("tex_scale", "p"),
+    ("tex_bytes", "n64"), ("tex_data", "p"),
+    ("n_lights", "n"), ("light_type", "p"), ("light_geom", "p"), ("light_steps", "p"), ("light_intensity", "p"),
+]
+_DTYPES = {"tex_off": np.int64, "tex_data": np.uint8}
+_F64 = {"leaf_minmax", "xform", "tri_geom", "tri_norm", "item_lo", "item_hi", "csg_bbox", "mat", "pat_inv", "pat_ab",
+        "pat_param", "pat_colors", "tex_scale", "light_geom", "light_intensity"}
+
+
+class SceneDesc(C.Structure):
+    _fields_ = [(n, C.c_int32 if k == "n" else (C.c_int64 if k == "n64" else _P)) for n, k in _DESC_FIELDS]
+
+
+class CameraDesc(C.Structure):
+    _fields_ = [("hsize", C.c_int32), ("vsize", C.c_int32), ("half_width", C.c_double),
+                ("half_height", C.c_double), ("pixel_size", C.c_double), ("inv_transform", C.c_double * 12)]
+
+
+class RenderOpts(C.Structure):
+    _fields_ = [("precision", C.c_int32), ("max_depth", C.c_int32), ("tile_size", C.c_int32),
+                ("reserved", C.c_int32), ("shade_eps", C.c_double), ("seed", C.c_uint64)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("rays", C.c_int64 * 4), ("kernel_ms", C.c_double)]
+
+
+class SceneInfo(C.Structure):
+    _fields_ = [("device", C.c_int32), ("bvh_nodes", C.c_int32), ("bvh_depth", C.c_int32),
+                ("bvh_max_leaf", C.c_int32), ("device_bytes_fp64", C.c_int64), ("device_bytes_fp32", C.c_int64)]
+
+
+EXPORTS = ["rtc_version", "rtc_device_count", "rtc_last_error", "rtc_scene_create", "rtc_scene_destroy",
+           "rtc_scene_get_info", "rtc_render", "rtc_render_tiles", "rtc_render_device", "rtc_quantize_device"]
+
+
+class RtcError(RuntimeError):
+    pass
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RtcError("librtc_hip.so is not built (run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "or `make -C ray_tracer_challenge_amd/csrc`); there is no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        L.rtc_last_error.restype = C.c_char_p
+        L.rtc_scene_create.argtypes = [C.POINTER(SceneDesc), C.c_int, C.POINTER(_P)]
+        L.rtc_scene_destroy.argtypes = [_P]
+        L.rtc_scene_destroy.restype = None
+        L.rtc_scene_get_info.argtypes = [_P, C.POINTER(SceneInfo)]
+        L.rtc_render.argtypes = [_P, C.POINTER(CameraDesc), C.POINTER(RenderOpts), _P, _P, C.POINTER(Stats)]
+        L.rtc_render_tiles.argtypes = [_P, C.POINTER(CameraDesc), C.POINTER(RenderOpts), C.c_int32, _P, _P, _P,
+                                       C.POINTER(Stats)]
+        L.rtc_render_device.argtypes = [_P, C.POINTER(CameraDesc), C.POINTER(RenderOpts), C.c_int32, _P, _P, _P, _P, _P]
+        L.rtc_quantize_device.argtypes = [_P, C.c_int32, C.c_int32, C.c_double, _P, _P]
+        _lib = L
+    return _lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise RtcError("rtc error %d: %s" % (rc, lib().rtc_last_error().decode("utf-8", "replace")))
+
+
+def device_count():
+    return int(lib().rtc_device_count())
+
+
+def make_camera(cam):
+    c = CameraDesc()
+    c.hsize, c.vsize = int(cam.hsize), int(cam.vsize)
+    c.half_width, c.half_height, c.pixel_size = float(cam.half_width), float(cam.half_height), float(cam.pixel_size)
+    t = np.asarray(getattr(cam.transform, "arr", cam.transform), dtype=np.float64)
+    inv = np.linalg.inv(t)[:3, :].reshape(12)      # inverse(cam.transform), renderer.py:747-748
+    for i in range(12):
+        c.inv_transform[i] = inv[i]
+    return c
+
+
+def make_opts(precision="fp64", max_depth=5, tile_size=32, shade_eps=0.0, seed=0):
+    bits = {"fp64": 64, "fp32": 32, 64: 64, 32: 32}.get(precision)
+    if bits is None:
+        raise ValueError("precision must be 'fp64' or 'fp32'")
+    return RenderOpts(bits, int(max_depth), int(tile_size), 0, float(shade_eps), int(seed))
+
+
+def make_desc(cs):
+    """CompiledScene -> (SceneDesc, keepalive list of arrays)."""
+    d = SceneDesc()
+    keep = []
+    for name, kind in _DESC_FIELDS:
+        if kind in ("n", "n64"):
+            setattr(d, name, int(cs.counts[name]))
+        else:
+            want = _DTYPES.get(name, np.float64 if name in _F64 else np.int32)
+            a = np.ascontiguousarray(cs.arrays[name], dtype=want)
+            keep.append(a)
+            setattr(d, name, a.ctypes.data_as(_P))
+    return d, keep
+
+
+class Scene(object):
+    """A compiled scene resident on one GPU (`rtc_scene*`)."""
+
+    def __init__(self, cs, device=0):
+        self.handle = _P()
+        self.cs = cs
+        d, keep = make_desc(cs)
+        _check(lib().rtc_scene_create(C.byref(d), int(device), C.byref(self.handle)))
+        self.device = device
+
+    def close(self):
+        if self.handle:
+            lib().rtc_scene_destroy(self.handle)
+            self.handle = _P()
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def info(self):
+        out = SceneInfo()
+        _check(lib().rtc_scene_get_info(self.handle, C.byref(out)))
+        return {k: getattr(out, k) for k, _ in SceneInfo._fields_}
+
+    def render(self, cam, precision="fp64", max_depth=5, want_ids=False, stats=None, shade_eps=0.0, seed=0):
+        """-> (rgb (hsize, vsize, 3) f64, ids (hsize, vsize) i32 or None)."""
+        c, o, st = make_camera(cam), make_opts(precision, max_depth, 32, shade_eps, seed), Stats()
+        rgb = np.zeros((c.hsize, c.vsize, 3), np.float64)
+        ids = np.full((c.hsize, c.vsize), -1, np.int32) if want_ids else None
+        _check(lib().rtc_render(self.handle, C.byref(c), C.byref(o), rgb.ctypes.data_as(_P),
+                                ids.ctypes.data_as(_P) if want_ids else None, C.byref(st)))
+        _fill_stats(stats, st)
+        return rgb, ids
+
+    def render_tiles(self, cam, tile_ids, precision="fp64", max_depth=5, tile_size=32, want_ids=False, stats=None,
+                     shade_eps=0.0, seed=0):
+        """Compact tiles -> (rgb (n, T, T, 3) [slot][ty][tx], ids (n, T, T) or None)."""
+        c, o, st = make_camera(cam), make_opts(precision, max_depth, tile_size, shade_eps, seed), Stats()
+        tiles = np.ascontiguousarray(tile_ids, dtype=np.int32)
+        n, T = tiles.size, tile_size
+        rgb = np.zeros((n, T, T, 3), np.float64)
+        ids = np.full((n, T, T), -1, np.int32) if want_ids else None
+        _check(lib().rtc_render_tiles(self.handle, C.byref(c), C.byref(o), n, tiles.ctypes.data_as(_P),
+                                      rgb.ctypes.data_as(_P), ids.ctypes.data_as(_P) if want_ids else None, C.byref(st)))
+        _fill_stats(stats, st)
+        return rgb, ids
+
+    def render_device(self, cam, rgb_ptr, ids_ptr=None, rays_ptr=None, tile_ids_ptr=None, n_tiles=0, precision="fp64",
+                      max_depth=5, tile_size=32, shade_eps=0.0, seed=0, stream=None):
+        """Asynchronous launch on device pointers (ints, e.g. torch `tensor.data_ptr()`)."""
+        c, o = make_camera(cam), make_opts(precision, max_depth, tile_size, shade_eps, seed)
+        _check(lib().rtc_render_device(self.handle, C.byref(c), C.byref(o), int(n_tiles), _P(tile_ids_ptr or None),
+                                       _P(rgb_ptr), _P(ids_ptr or None), _P(rays_ptr or None), _P(stream or None)))
+
+
+def _fill_stats(stats, st):
+    if stats is not None:
+        stats["rays"] = [int(v) for v in st.rays]
+        stats["kernel_ms"] = float(st.kernel_ms)
+
+
+def tiles_for(hsize, vsize, tile_size=32):
+    tx, ty = (hsize + tile_size - 1) // tile_size, (vsize + tile_size - 1) // tile_size
+    return tx, ty
+
+
+def scatter_tiles(dst_rgb, dst_ids, tile_ids, rgb_tiles, id_tiles, tile_size=32):
+    """Un-permute compact tiles ([slot][ty][tx]) into the [x][y] frame."""
+    hsize, vsize = dst_rgb.shape[0], dst_rgb.shape[1]
+    tiles_x, _ = tiles_for(hsize, vsize, tile_size)
+    T = tile_size
+    for k, tile in enumerate(np.asarray(tile_ids)):
+        x0, y0 = (int(tile) % tiles_x) * T, (int(tile) // tiles_x) * T
+        w, h = min(T, hsize - x0), min(T, vsize - y0)
+        dst_rgb[x0:x0 + w, y0:y0 + h] = np.transpose(rgb_tiles[k, :h, :w], (1, 0, 2))
+        if dst_ids is not None and id_tiles is not None:
+            dst_ids[x0:x0 + w, y0:y0 + h] = id_tiles[k, :h, :w].T
+
+
+def render_on_devices(cs, cam, devices, precision="fp64", max_depth=5, want_ids=False, stats=None, tile_size=32):
+    """One process, several GPUs: tile i goes to devices[i % n]; host-side gather."""
+    tx, ty = tiles_for(cam.hsize, cam.vsize, tile_size)
+    all_tiles = np.arange(tx * ty, dtype=np.int32)
+    rgb = np.zeros((cam.hsize, cam.vsize, 3), np.float64)
+    ids = np.full((cam.hsize, cam.vsize), -1, np.int32) if want_ids else None
+    total = [0, 0, 0, 0]
+    for k, dev in enumerate(devices):
+        mine = all_tiles[k::len(devices)]
+        if mine.size == 0:
+            continue
+        st = {}
+        with Scene(cs, device=dev) as sc:
+            r, i = sc.render_tiles(cam, mine, precision, max_depth, tile_size, want_ids, st)
+        scatter_tiles(rgb, ids, mine, r, i, tile_size)
+        total = [a + b for a, b in zip(total, st["rays"])]
+    if stats is not None:
+        stats["rays"] = total
+    return rgb, ids

@@ -1,0 +1,409 @@
+"""Scene compiler: a tree of shape objects -> the flat fp64 arrays of `rtc_scene_desc`.
+
+Input is duck-typed: this package's `shapes`/`renderer` objects or the reference's own
+(`World.contains`, `.transform.arr`, `.material.*`, `.children`, `.left/.right/.op`,
+`.minimum/.maximum/.closed`, `.p1..p3`, `.n1..n3`; classes are told apart by class name).
+
+What it does, once per scene, on the host:
+  * numbers the primitive shapes ("leaves") depth-first from `world.contains`;
+  * collapses each leaf's chain of per-level inverses (reference shapes.py:271-273 applied at
+    every tree level, :282-286) into ONE world->object 3x4 -- its transpose is the collapsed
+    `normal_to_world` chain (:288-296), since per-level renormalisation only rescales;
+  * moves triangles to world space (points by object->world, normals by the transposed
+    world->object) and rescales the Moller-Trumbore determinant epsilon by |det(object->world)|
+    so the `abs(det) < EPSILON` rejection (:815, :863) is the same test;
+  * computes a world-space AABB per leaf / per top-most CSG (the library builds its BVH over
+    them); planes and other unbounded things go to a list tested for every ray;
+  * records every top-most CSG as a post-ordered list of nodes with contiguous leaf ranges,
+    each node with its reference `bounds()` box (:391-396) and world->csg-local matrix;
+  * turns each material's pattern tree into a postfix program over pattern nodes.
+"""
+import numpy as np
+
+EPSILON = 0.000001
+
+K_SPHERE, K_PLANE, K_CUBE, K_CYLINDER, K_CONE, K_TRIANGLE, K_CSG_ROOT = 0, 1, 2, 3, 4, 5, 8
+_KIND = {"Sphere": K_SPHERE, "Plane": K_PLANE, "Cube": K_CUBE, "Cylinder": K_CYLINDER, "Cone": K_CONE,
+         "Triangle": K_TRIANGLE, "SmoothTriangle": K_TRIANGLE}
+_CSG_OP = {"CSGUnion": 0, "CSGIntersect": 1, "CSGDifference": 2}
+_PAT_SIMPLE = {"Pattern": 0, "Checkers": 1, "Gradient": 2, "RadialGradient": 3, "Ring": 4, "Stripe": 5}
+_TWO_COLOR = ("Checkers", "Gradient", "RadialGradient", "Ring", "Stripe")
+_UV = {"UVChecker": 20, "UVAlignCheck": 21, "UVTexturePattern": 22}
+_UVMAP = {"PlaneUVMap": 9, "SphereUVMap": 10}
+OP_EVAL, OP_EVAL_AB, OP_BLEND = 0, 1, 2
+_MAX_HITS = {K_SPHERE: 2, K_PLANE: 1, K_CUBE: 2, K_CYLINDER: 4, K_CONE: 4, K_TRIANGLE: 1}
+
+
+def prim_code(kind, noshadow, index):
+    return np.int32(np.uint32((kind << 28) | ((1 if noshadow else 0) << 27) | (index & 0x07FFFFFF)).view(np.int32))
+
+
+def _a(x, n=None):
+    a = np.asarray(getattr(x, "arr", x), dtype=np.float64)
+    return a if n is None else a[:n]
+
+
+def _cname(x):
+    return x.__name__ if isinstance(x, type) else type(x).__name__
+
+
+class CompiledScene(object):
+    """`arrays`: name -> contiguous ndarray, named as the fields of `rtc_scene_desc`;
+    `counts`: the n_* fields; `leaf_objects`: the shape object behind each leaf id."""
+
+    def __init__(self):
+        self.arrays = {}
+        self.counts = {}
+        self.leaf_objects = []
+
+
+class _Compiler(object):
+    def __init__(self):
+        self.leaf_kind, self.leaf_xform, self.leaf_material, self.leaf_tri = [], [], [], []
+        self.leaf_minmax, self.leaf_closed, self.leaf_objects = [], [], []
+        self.leaf_lo, self.leaf_hi = [], []          # world AABB per leaf (triangles filled in bulk later)
+        self.xforms, self._xform_of = [], {}
+        self.tri_rows, self.tri_xform, self.tri_leaf, self.tri_flat = [], [], [], []
+        self.items, self.unbounded = [], []          # (kind, leaf or csg root)
+        self.csg_roots, self.csg_nodes, self.csg_bbox = [], [], []
+        self.materials, self._mat_of = [], {}
+        self.pat_nodes, self._pat_of = [], {}
+        self.programs, self.instr = [], []
+        self.textures, self._tex_of = [], {}
+        self._inv_cache = {}
+
+    # ---- transforms ------------------------------------------------------------------
+    def _inverse(self, t):
+        arr = _a(t)
+        key = arr.tobytes()
+        inv = self._inv_cache.get(key)
+        if inv is None:
+            inv = np.linalg.inv(arr)      # matrix.py:393
+            self._inv_cache[key] = inv
+        return inv
+
+    def _xform(self, m):
+        key = m.tobytes()
+        idx = self._xform_of.get(key)
+        if idx is None:
+            idx = self._xform_of[key] = len(self.xforms)
+            self.xforms.append(m)
+        return idx
+
+    # ---- tree walk -------------------------------------------------------------------
+    def shape(self, obj, m_parent, in_csg):
+        name = type(obj).__name__
+        inv = self._inverse(obj.transform)
+        m = inv if m_parent is None else inv @ m_parent
+        if name == "Group":
+            for c in list(obj.children):
+                self.shape(c, m, in_csg)
+        elif name == "CSG":
+            if in_csg:
+                self._csg_node(obj, m)
+            else:
+                first_node, first_leaf = len(self.csg_nodes), len(self.leaf_kind)
+                self._csg_node(obj, m)
+                self.csg_roots.append([first_node, len(self.csg_nodes) - first_node, first_leaf, len(self.leaf_kind)])
+                hits = sum(_MAX_HITS[k] for k in self.leaf_kind[first_leaf:])
+                if hits > 32:
+                    raise NotImplementedError("a CSG object whose leaves can produce %d hits per ray "
+                                              "(limit 32, RTC_MAX_CSG_HITS)" % hits)
+        elif name in _KIND:
+            self._leaf(obj, name, m, in_csg)
+        else:
+            raise ValueError("unknown shape class " + name)
+
+    def _csg_node(self, obj, m):
+        l0 = len(self.leaf_kind)
+        self.shape(obj.left, m, True)
+        l1 = len(self.leaf_kind)
+        self.shape(obj.right, m, True)
+        l2 = len(self.leaf_kind)
+        b = obj.bounds()
+        self.csg_nodes.append([_CSG_OP[_cname(obj.op)], l0, l1, l2, self._xform(m)])
+        self.csg_bbox.append(list(_a(b.min, 3)) + list(_a(b.max, 3)))
+
+    def _leaf(self, obj, name, m, in_csg):
+        kind = _KIND[name]
+        leaf = len(self.leaf_kind)
+        mat = self._material(obj.material)
+        self.leaf_kind.append(kind)
+        self.leaf_xform.append(self._xform(m))
+        self.leaf_material.append(mat)
+        self.leaf_objects.append(obj)
+        lo, hi, minmax, closed = None, None, (0.0, 0.0), 0
+        if kind == K_TRIANGLE:
+            self.leaf_tri.append(len(self.tri_rows))
+            flat = name == "Triangle"
+            if flat:
+                row = np.concatenate([_a(obj.p1, 3), _a(obj.p2, 3), _a(obj.p3, 3), np.zeros(9)])
+            else:
+                row = np.concatenate([_a(obj.p1, 3), _a(obj.p2, 3), _a(obj.p3, 3),
+                                      _a(obj.n1, 3), _a(obj.n2, 3), _a(obj.n3, 3)])
+            self.tri_rows.append(row)
+            self.tri_xform.append(self.leaf_xform[-1])
+            self.tri_leaf.append(leaf)
+            self.tri_flat.append(flat)
+        else:
+            self.leaf_tri.append(-1)
+            if kind in (K_CYLINDER, K_CONE):
+                minmax = (float(obj.minimum), float(obj.maximum))
+                closed = 1 if obj.closed else 0
+            lo, hi = self._analytic_bounds(kind, minmax, m)
+        self.leaf_minmax.append(minmax)
+        self.leaf_closed.append(closed)
+        self.leaf_lo.append(lo)
+        self.leaf_hi.append(hi)
+        if not in_csg:
+            (self.items if (kind == K_TRIANGLE or lo is not None) else self.unbounded).append((kind, leaf))
+
+    @staticmethod
+    def _analytic_bounds(kind, minmax, m):
+        """World AABB of the leaf's local bounds (shapes.py:298-300, 561-562, 708-713, 795-796)."""
+        if kind == K_PLANE:
+            return None, None
+        if kind in (K_SPHERE, K_CUBE):
+            l, h = np.array([-1.0, -1, -1]), np.array([1.0, 1, 1])
+        else:
+            if not (np.isfinite(minmax[0]) and np.isfinite(minmax[1])):
+                return None, None
+            r = 1.0 if kind == K_CYLINDER else max(abs(minmax[0]), abs(minmax[1]))
+            l, h = np.array([-r, minmax[0], -r]), np.array([r, minmax[1], r])
+        a = np.linalg.inv(m)
+        corners = np.array([[x, y, z, 1.0] for x in (l[0], h[0]) for y in (l[1], h[1]) for z in (l[2], h[2])])
+        w = corners @ a.T
+        return w[:, :3].min(axis=0), w[:, :3].max(axis=0)
+
+    # ---- materials and patterns --------------------------------------------------------
+    def _material(self, m):
+        idx = self._mat_of.get(id(m))
+        if idx is None:
+            idx = self._mat_of[id(m)] = len(self.materials)
+            prog = -1 if m.pattern is None else self._program(m.pattern)
+            self.materials.append((list(_a(m.color, 3)) + [float(m.ambient), float(m.diffuse), float(m.specular),
+                                   float(m.shininess), float(m.reflective), float(m.transparency),
+                                   float(m.refractive_index)], 1 if m.casts_shadow else 0, prog, m))
+        return idx
+
+    def _program(self, p):
+        code = []
+        self._emit(p, code)
+        self.programs.append((len(self.instr), len(code)))
+        self.instr.extend(code)
+        return len(self.programs) - 1
+
+    def _emit(self, p, code):
+        name = type(p).__name__
+        if name == "BlendedPattern":                     # shapes.py:1874-1877
+            self._emit(p.p1, code)
+            self._emit(p.p2, code)
+            code.append((OP_BLEND, 0))
+        elif name == "NestedPattern":                    # shapes.py:1892-1895
+            if p.p2 is p.p1 or p.p3 is p.p1:
+                raise NotImplementedError("NestedPattern whose primary is also its own sub-pattern is "
+                                          "stateful in the reference (it overwrites p1.a/p1.b while evaluating p1)")
+            if type(p.p1).__name__ in _TWO_COLOR:
+                self._emit(p.p2, code)
+                self._emit(p.p3, code)
+                code.append((OP_EVAL_AB, self._pat_node(p.p1)))
+            else:
+                # the colours written into p1.a / p1.b are never read by this kind of primary
+                self._emit(p.p1, code)
+        elif name == "PerturbedPattern":
+            raise NotImplementedError("PerturbedPattern needs the PyPI `noise` package's pnoise3 "
+                                      "(parity unpinned, SURVEY.md 8c); not in the compiled path")
+        else:
+            code.append((OP_EVAL, self._pat_node(p)))
+
+    def _pat_node(self, p):
+        idx = self._pat_of.get(id(p))
+        if idx is not None:
+            return idx
+        idx = self._pat_of[id(p)] = len(self.pat_nodes)
+        name = type(p).__name__
+        rec = {"type": None, "inv": self._inverse(p.transform), "ab": list(_a(p.a, 3)) + list(_a(p.b, 3)),
+               "child": [-1] * 6, "param": [0.0] * 4, "colors": [0.0] * 15, "tex": -1}
+        self.pat_nodes.append(rec)
+        if name in _PAT_SIMPLE:
+            rec["type"] = _PAT_SIMPLE[name]
+        elif name in _UV:
+            rec["type"] = _UV[name]
+            if name == "UVChecker":
+                rec["param"][:2] = [float(p.width), float(p.height)]
+            elif name == "UVAlignCheck":
+                rec["colors"] = [float(x) for c in (p.main, p.ul, p.ur, p.bl, p.br) for x in c]
+            else:
+                rec["tex"] = self._texture(p.canvas)
+        elif name == "TextureMapPattern":
+            rec["type"] = _UVMAP[_cname(p.uv_map)]
+            rec["child"][0] = self._pat_node(p.uv_pattern)
+        elif name == "CylinderMapPattern":
+            rec["type"] = 11
+            rec["child"][:2] = [self._pat_node(f) for f in p.faces]
+        elif name == "CubeMapPattern":
+            rec["type"] = 12
+            rec["child"][:6] = [self._pat_node(f) for f in p.faces]
+        else:
+            raise ValueError("unknown pattern class " + name)
+        return idx
+
+    def _texture(self, tc):
+        idx = self._tex_of.get(id(tc))
+        if idx is None:
+            px = np.asarray(tc.pixels)
+            if px.ndim != 3 or px.shape[2] < 3:
+                raise ValueError("image textures must be RGB(A); the reference indexes three channels (canvas.py:52-54)")
+            idx = self._tex_of[id(tc)] = len(self.textures)
+            self.textures.append((np.ascontiguousarray(px[:, :, :3].astype(np.uint8)), float(np.max(px))))
+        return idx
+
+    # ---- assembly ------------------------------------------------------------------------
+    def finish(self, lights):
+        f64, i32 = np.float64, np.int32
+        cs = CompiledScene()
+        A, C = cs.arrays, cs.counts
+        n_leaves = len(self.leaf_kind)
+        xf = np.array(self.xforms, f64).reshape(-1, 4, 4) if self.xforms else np.zeros((0, 4, 4))
+        mat_shadow = np.array([m[1] for m in self.materials] or [1], i32)
+        leaf_material = np.array(self.leaf_material, i32).reshape(-1)
+        leaf_noshadow = (mat_shadow[leaf_material] == 0) if n_leaves else np.zeros(0, bool)
+
+        # triangles -> world space, in bulk per transform
+        n_tris = len(self.tri_rows)
+        tri_geom = np.zeros((max(n_tris, 1), 12))
+        tri_norm = np.zeros((max(n_tris, 1), 12))
+        tri_lo = np.zeros((n_tris, 3))
+        tri_hi = np.zeros((n_tris, 3))
+        if n_tris:
+            rows = np.array(self.tri_rows, f64)
+            txf = np.array(self.tri_xform, i32)
+            flat = np.array(self.tri_flat, bool)
+            for xi in np.unique(txf):
+                sel = np.nonzero(txf == xi)[0]
+                m = xf[xi]
+                a = np.linalg.inv(m)                       # object -> world
+                a3, t3, m3 = a[:3, :3], a[:3, 3], m[:3, :3]
+                r = rows[sel]
+                p = [r[:, 3 * k:3 * k + 3] @ a3.T + t3 for k in range(3)]
+                e1o, e2o = r[:, 3:6] - r[:, 0:3], r[:, 6:9] - r[:, 0:3]
+                fn = np.cross(e2o, e1o)                    # shapes.py:807
+                with np.errstate(invalid="ignore", divide="ignore"):
+                    fn = fn * (1.0 / np.sqrt(np.sum(fn * fn, axis=1, keepdims=True)))
+                fl = flat[sel]
+                normals = [np.where(fl[:, None], fn, r[:, 9 + 3 * k:12 + 3 * k]) @ m3 for k in range(3)]  # M^T n
+                g = tri_geom[sel]
+                g[:, 0:3], g[:, 3:6], g[:, 6:9] = p[0], p[1] - p[0], p[2] - p[0]
+                g[:, 9] = EPSILON * abs(np.linalg.det(a3))
+                tri_geom[sel] = g
+                nn = tri_norm[sel]
+                nn[:, 0:3], nn[:, 3:6], nn[:, 6:9] = normals
+                tri_norm[sel] = nn
+                pts = np.stack(p, axis=0)
+                tri_lo[sel], tri_hi[sel] = pts.min(axis=0), pts.max(axis=0)
+            tl = np.array(self.tri_leaf, i32)
+            for k, leaf in enumerate(tl):
+                self.leaf_lo[leaf], self.leaf_hi[leaf] = tri_lo[k], tri_hi[k]
+
+        # items for the BVH / the unbounded list
+        leaf_tri = np.array(self.leaf_tri, i32).reshape(-1)
+        item_prim, item_lo, item_hi, unb = [], [], [], []
+        for kind, leaf in self.items:
+            idx = int(leaf_tri[leaf]) if kind == K_TRIANGLE else leaf
+            item_prim.append(prim_code(kind, leaf_noshadow[leaf], idx))
+            item_lo.append(self.leaf_lo[leaf])
+            item_hi.append(self.leaf_hi[leaf])
+        for kind, leaf in self.unbounded:
+            unb.append(prim_code(kind, leaf_noshadow[leaf], leaf))
+        for root, (_, _, l0, l2) in enumerate(self.csg_roots):
+            los = [self.leaf_lo[l] for l in range(l0, l2)]
+            if any(b is None for b in los) or not all(np.all(np.isfinite(b)) for b in los):
+                unb.append(prim_code(K_CSG_ROOT, False, root))
+            else:
+                item_prim.append(prim_code(K_CSG_ROOT, False, root))
+                item_lo.append(np.min(np.array(los), axis=0))
+                item_hi.append(np.max(np.array([self.leaf_hi[l] for l in range(l0, l2)]), axis=0))
+        # an item with non-finite bounds (degenerate transform) is tested for every ray instead
+        if item_prim:
+            lo_a, hi_a = np.array(item_lo, f64).reshape(-1, 3), np.array(item_hi, f64).reshape(-1, 3)
+            ok = np.all(np.isfinite(lo_a), axis=1) & np.all(np.isfinite(hi_a), axis=1)
+            if not ok.all():
+                unb.extend(p for p, k in zip(item_prim, ok) if not k)
+                item_prim = [p for p, k in zip(item_prim, ok) if k]
+                item_lo, item_hi = lo_a[ok], hi_a[ok]
+            else:
+                item_lo, item_hi = lo_a, hi_a
+
+        def arr(x, dt, shape):
+            a = np.ascontiguousarray(np.array(x, dt).reshape(shape))
+            return a if a.size else np.zeros([max(1, s) if s != -1 else 1 for s in shape], dt)
+
+        A["leaf_kind"] = arr(self.leaf_kind, i32, (-1,))
+        A["leaf_xform"] = arr(self.leaf_xform, i32, (-1,))
+        A["leaf_material"] = arr(self.leaf_material, i32, (-1,))
+        A["leaf_tri"] = arr(self.leaf_tri, i32, (-1,))
+        A["leaf_minmax"] = arr(self.leaf_minmax, f64, (-1, 2))
+        A["leaf_closed"] = arr(self.leaf_closed, i32, (-1,))
+        A["xform"] = arr(xf[:, :3, :], f64, (-1, 12))
+        A["tri_geom"] = np.ascontiguousarray(tri_geom)
+        A["tri_norm"] = np.ascontiguousarray(tri_norm)
+        A["tri_leaf"] = arr(self.tri_leaf, i32, (-1,))
+        A["item_prim"] = arr(item_prim, i32, (-1,))
+        A["item_lo"] = arr(item_lo, f64, (-1, 3))
+        A["item_hi"] = arr(item_hi, f64, (-1, 3))
+        A["unbounded_prim"] = arr(unb, i32, (-1,))
+        A["csg_root"] = arr(self.csg_roots, i32, (-1, 4))
+        A["csg_node"] = arr(self.csg_nodes, i32, (-1, 5))
+        A["csg_bbox"] = arr(self.csg_bbox, f64, (-1, 6))
+        A["mat"] = arr([m[0] for m in self.materials], f64, (-1, 10))
+        A["mat_shadow"] = arr([m[1] for m in self.materials], i32, (-1,))
+        A["mat_program"] = arr([m[2] for m in self.materials], i32, (-1,))
+        P = self.pat_nodes
+        A["pat_type"] = arr([p["type"] for p in P], i32, (-1,))
+        A["pat_inv"] = arr([p["inv"][:3, :] for p in P], f64, (-1, 12))
+        A["pat_ab"] = arr([p["ab"] for p in P], f64, (-1, 6))
+        A["pat_child"] = arr([p["child"] for p in P], i32, (-1, 6))
+        A["pat_param"] = arr([p["param"] for p in P], f64, (-1, 4))
+        A["pat_colors"] = arr([p["colors"] for p in P], f64, (-1, 15))
+        A["pat_tex"] = arr([p["tex"] for p in P], i32, (-1,))
+        A["prog_off"] = arr([p[0] for p in self.programs], i32, (-1,))
+        A["prog_len"] = arr([p[1] for p in self.programs], i32, (-1,))
+        A["instr"] = arr(self.instr, i32, (-1, 2))
+        offs, off = [], 0
+        for px, _ in self.textures:
+            offs.append(off)
+            off += px.size
+        A["tex_off"] = arr(offs, np.int64, (-1,))
+        A["tex_w"] = arr([t[0].shape[1] for t in self.textures], i32, (-1,))
+        A["tex_h"] = arr([t[0].shape[0] for t in self.textures], i32, (-1,))
+        A["tex_scale"] = arr([t[1] for t in self.textures], f64, (-1,))
+        A["tex_data"] = (np.concatenate([t[0].ravel() for t in self.textures]) if self.textures else np.zeros(1, np.uint8))
+        typ, geom, steps, inten = [], [], [], []
+        for l in lights:
+            if hasattr(l, "position"):
+                typ.append(0)
+                geom.append(list(_a(l.position, 3)) + [0.0] * 6)
+                steps.append([1, 1, 0])
+            else:
+                typ.append(1)
+                geom.append(list(_a(l.corner, 3)) + list(_a(l.uvec, 3)) + list(_a(l.vvec, 3)))
+                steps.append([int(l.usteps), int(l.vsteps), 1 if l.jitter else 0])
+            inten.append(list(_a(l.intensity, 3)))
+        A["light_type"] = arr(typ, i32, (-1,))
+        A["light_geom"] = arr(geom, f64, (-1, 9))
+        A["light_steps"] = arr(steps, i32, (-1, 3))
+        A["light_intensity"] = arr(inten, f64, (-1, 3))
+        C.update(n_leaves=n_leaves, n_xforms=len(self.xforms), n_tris=n_tris, n_items=len(item_prim),
+                 n_unbounded=len(unb), n_csg_roots=len(self.csg_roots), n_csg_nodes=len(self.csg_nodes),
+                 n_materials=len(self.materials), n_pat_nodes=len(P), n_programs=len(self.programs),
+                 n_instr=len(self.instr), n_textures=len(self.textures), tex_bytes=off, n_lights=len(lights))
+        cs.leaf_objects = self.leaf_objects
+        return cs
+
+
+def compile_scene(world):
+    """World (lights + contains) -> CompiledScene."""
+    c = _Compiler()
+    for obj in world.contains:
+        c.shape(obj, None, False)
+    return c.finish(list(world.lights or []))

@@ -1,0 +1,523 @@
+// rtc_api.hip -- the C ABI of include/rtc_api.h: scene upload, BVH build, kernel launches.
+// One translation unit, built by hipcc for gfx950 into librtc_hip.so.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/rtc_api.h"
+#include "rtc_bvh.hpp"
+#include "rtc_device.hpp"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess) return fail(RTC_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// kernels
+// ---------------------------------------------------------------------------------------------
+template <class R>
+__global__ __launch_bounds__(RTC_BLOCK) void trace_kernel(rtc::DScene<R> S, rtc::DCamera<R> cam, rtc::DFrame F, R shade_eps) {
+    __shared__ int s_stack[RTC_BVH_STACK * RTC_BLOCK];
+    int* stack = s_stack + threadIdx.x;
+    const int T = F.tile_size, per_tile = T * T, sub = T / 8;
+    long long w = (long long)blockIdx.x * RTC_BLOCK + threadIdx.x;
+    int slot = (int)(w / per_tile), within = (int)(w % per_tile);
+    rtc::Counters<R> cnt = {{0, 0, 0, 0}};
+    if (slot < F.n_tiles) {
+        int tile = F.tile_ids ? F.tile_ids[slot] : slot;
+        int tx0 = (tile % F.tiles_x) * T, ty0 = (tile / F.tiles_x) * T;
+        int sb = within >> 6, l = within & 63;          // one wave = one 8x8 pixel block
+        int x = tx0 + (sb % sub) * 8 + (l & 7), y = ty0 + (sb / sub) * 8 + (l >> 3);
+        if (x < cam.hsize && y < cam.vsize) {
+            rtc::Ray<R> ray = rtc::ray_for_pixel(cam, x, y);
+            cnt.c[0] = 1;
+            int hit_leaf;
+            rtc::V3<R> c = rtc::trace_pixel(S, ray, F.max_depth, shade_eps, stack, cnt, F.seed,
+                                            (uint32_t)(y * cam.hsize + x), hit_leaf);
+            size_t o;
+            if (F.tile_ids) {
+                int lx = x - tx0, ly = y - ty0;
+                o = (size_t)slot * per_tile + (size_t)ly * T + lx;
+            } else {
+                o = (size_t)x * cam.vsize + y;   // canvas order [x][y] (canvas.py:60)
+            }
+            F.rgb[3 * o] = (double)c.x; F.rgb[3 * o + 1] = (double)c.y; F.rgb[3 * o + 2] = (double)c.z;
+            if (F.hit_id) F.hit_id[o] = hit_leaf;
+        }
+    }
+    if (F.rays) {   // block-level reduction of the ray counters, then 4 atomics per block
+        __syncthreads();
+        unsigned int* red = reinterpret_cast<unsigned int*>(s_stack);
+        for (int k = 0; k < 4; k++) {
+            unsigned int v = cnt.c[k];
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+            if ((threadIdx.x & 63) == 0) red[k * (RTC_BLOCK / 64) + (threadIdx.x >> 6)] = v;
+        }
+        __syncthreads();
+        if (threadIdx.x < 4) {
+            unsigned long long s = 0;
+            for (int q = 0; q < RTC_BLOCK / 64; q++) s += red[threadIdx.x * (RTC_BLOCK / 64) + q];
+            if (s) atomicAdd(F.rays + threadIdx.x, s);
+        }
+    }
+}
+
+// canvas.py:133-156
+__global__ void quantize_kernel(const double* rgb, int hsize, int vsize, double maxc, uint8_t* out) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    long long n = (long long)hsize * vsize * 3;
+    if (i >= n) return;
+    int c = (int)(i % 3);
+    long long p = i / 3;
+    int x = (int)(p % hsize), y = (int)(p / hsize);
+    double v = rgb[((size_t)x * vsize + y) * 3 + c];
+    int q;
+    if (v >= maxc) q = 255;
+    else if (v <= 0) q = 0;
+    else q = (int)(v * 255 / maxc + 0.5);
+    out[i] = (uint8_t)q;
+}
+
+// ---------------------------------------------------------------------------------------------
+// device buffers
+// ---------------------------------------------------------------------------------------------
+struct DeviceArena {
+    std::vector<void*> ptrs;
+    size_t bytes = 0;
+    template <class T> int upload(const T* host, size_t n, const T** out) {
+        void* d = nullptr;
+        size_t sz = (n ? n : 1) * sizeof(T);
+        HIP_TRY(hipMalloc(&d, sz));
+        ptrs.push_back(d);
+        bytes += sz;
+        if (n) HIP_TRY(hipMemcpy(d, host, n * sizeof(T), hipMemcpyHostToDevice));
+        *out = static_cast<const T*>(d);
+        return 0;
+    }
+    void release() {
+        for (void* p : ptrs) (void)hipFree(p);
+        ptrs.clear();
+    }
+};
+
+template <class R> std::vector<R> cast_vec(const double* p, size_t n) {
+    std::vector<R> v(n);
+    for (size_t i = 0; i < n; i++) v[i] = (R)p[i];
+    return v;
+}
+
+// boxes padded outward so that neither rounding in the compiler nor in the slab test can
+// reject a leaf the leaf test itself would accept
+template <class R> std::vector<R> pad_boxes(const std::vector<double>& box) {
+    const double rel = sizeof(R) == 4 ? 2e-5 : 1e-9;
+    std::vector<R> out(box.size());
+    for (size_t i = 0; i < box.size(); i++) {
+        bool is_hi = (i % 6) >= 3;
+        double v = box[i];
+        if (std::isfinite(v)) {
+            double pad = rel * std::max(1.0, std::fabs(v));
+            v = is_hi ? v + pad : v - pad;
+            R r = (R)v;
+            if (is_hi && (double)r < v) r = std::nextafter(r, std::numeric_limits<R>::infinity());
+            if (!is_hi && (double)r > v) r = std::nextafter(r, -std::numeric_limits<R>::infinity());
+            out[i] = r;
+        } else {
+            out[i] = (R)v;
+        }
+    }
+    return out;
+}
+
+}  // namespace
+
+struct rtc_scene {
+    int device = 0;
+    int n_leaves = 0;
+    rtc::Bvh bvh_info;   // sizes only (vectors cleared after upload)
+    int bvh_nodes = 0, bvh_depth = 0, bvh_max_leaf = 0;
+    DeviceArena mem64, mem32, shared;
+    rtc::DScene<double> d64;
+    rtc::DScene<float> d32;
+    bool has_jitter = false;
+};
+
+namespace {
+
+template <class R>
+int upload_real(const rtc_scene_desc& d, const std::vector<double>& node_box, DeviceArena& A, rtc::DScene<R>& S) {
+#define UP_REAL(field, src, count)                                             \
+    do {                                                                       \
+        std::vector<R> tmp_ = cast_vec<R>((src), (size_t)(count));             \
+        if (int rc_ = A.upload(tmp_.data(), tmp_.size(), &S.field)) return rc_; \
+    } while (0)
+    UP_REAL(leaf_minmax, d.leaf_minmax, 2 * (size_t)d.n_leaves);
+    UP_REAL(xform, d.xform, 12 * (size_t)d.n_xforms);
+    UP_REAL(tri_geom, d.tri_geom, 12 * (size_t)d.n_tris);
+    UP_REAL(tri_norm, d.tri_norm, 12 * (size_t)d.n_tris);
+    UP_REAL(csg_bbox, d.csg_bbox, 6 * (size_t)d.n_csg_nodes);
+    UP_REAL(mat, d.mat, 10 * (size_t)d.n_materials);
+    UP_REAL(pat_inv, d.pat_inv, 12 * (size_t)d.n_pat_nodes);
+    UP_REAL(pat_ab, d.pat_ab, 6 * (size_t)d.n_pat_nodes);
+    UP_REAL(pat_param, d.pat_param, 4 * (size_t)d.n_pat_nodes);
+    UP_REAL(pat_colors, d.pat_colors, 15 * (size_t)d.n_pat_nodes);
+    UP_REAL(tex_scale, d.tex_scale, (size_t)d.n_textures);
+    UP_REAL(light_geom, d.light_geom, 9 * (size_t)d.n_lights);
+    UP_REAL(light_intensity, d.light_intensity, 3 * (size_t)d.n_lights);
+#undef UP_REAL
+    std::vector<R> nb = pad_boxes<R>(node_box);
+    return A.upload(nb.data(), nb.size(), &S.node_box);
+}
+
+int validate(const rtc_scene_desc& d) {
+    if (d.n_leaves < 0 || d.n_xforms < 0 || d.n_tris < 0 || d.n_items < 0 || d.n_unbounded < 0 || d.n_materials < 0 ||
+        d.n_lights < 0 || d.n_csg_roots < 0 || d.n_csg_nodes < 0 || d.n_pat_nodes < 0 || d.n_programs < 0 ||
+        d.n_instr < 0 || d.n_textures < 0)
+        return fail(RTC_ERR_INVALID, "negative count in scene description");
+    if (d.n_leaves > 0x07FFFFFF || d.n_tris > 0x07FFFFFF) return fail(RTC_ERR_LIMIT, "more than 2^27-1 leaves");
+    if (d.n_items > (1 << 27)) return fail(RTC_ERR_LIMIT, "more than 2^27 BVH items");
+    for (int i = 0; i < d.n_leaves; i++) {
+        int k = d.leaf_kind[i];
+        if (k < RTC_SPHERE || k > RTC_TRIANGLE) return fail(RTC_ERR_INVALID, "leaf %d: unknown kind %d", i, k);
+        if (d.leaf_xform[i] < 0 || d.leaf_xform[i] >= d.n_xforms) return fail(RTC_ERR_INVALID, "leaf %d: xform row out of range", i);
+        if (d.leaf_material[i] < 0 || d.leaf_material[i] >= d.n_materials) return fail(RTC_ERR_INVALID, "leaf %d: material out of range", i);
+        if (k == RTC_TRIANGLE && (d.leaf_tri[i] < 0 || d.leaf_tri[i] >= d.n_tris)) return fail(RTC_ERR_INVALID, "leaf %d: triangle row out of range", i);
+    }
+    for (int i = 0; i < d.n_tris; i++)
+        if (d.tri_leaf[i] < 0 || d.tri_leaf[i] >= d.n_leaves) return fail(RTC_ERR_INVALID, "triangle %d: leaf out of range", i);
+    auto check_prim = [&](int32_t code, const char* what, int i) -> int {
+        rtc::PrimCode* dummy = nullptr; (void)dummy;
+        int kind = (int)((uint32_t)code >> 28), idx = (int)((uint32_t)code & 0x07FFFFFFu);
+        if (kind == RTC_TRIANGLE) { if (idx >= d.n_tris) return fail(RTC_ERR_INVALID, "%s %d: triangle row out of range", what, i); }
+        else if (kind == RTC_CSG_ROOT) { if (idx >= d.n_csg_roots) return fail(RTC_ERR_INVALID, "%s %d: CSG root out of range", what, i); }
+        else if (kind <= RTC_CONE) { if (idx >= d.n_leaves || d.leaf_kind[idx] != kind) return fail(RTC_ERR_INVALID, "%s %d: leaf/kind mismatch", what, i); }
+        else return fail(RTC_ERR_INVALID, "%s %d: unknown prim kind %d", what, i, kind);
+        return 0;
+    };
+    for (int i = 0; i < d.n_items; i++) {
+        if (int rc = check_prim(d.item_prim[i], "item", i)) return rc;
+        for (int k = 0; k < 3; k++)
+            if (!std::isfinite(d.item_lo[3 * i + k]) || !std::isfinite(d.item_hi[3 * i + k]))
+                return fail(RTC_ERR_INVALID, "item %d: non-finite bounds (unbounded things go in unbounded_prim)", i);
+    }
+    for (int i = 0; i < d.n_unbounded; i++)
+        if (int rc = check_prim(d.unbounded_prim[i], "unbounded", i)) return rc;
+    for (int i = 0; i < d.n_csg_roots; i++) {
+        const int32_t* r = d.csg_root + 4 * i;
+        if (r[0] < 0 || r[1] < 1 || r[0] + r[1] > d.n_csg_nodes || r[2] < 0 || r[3] > d.n_leaves || r[2] > r[3])
+            return fail(RTC_ERR_INVALID, "CSG root %d: ranges out of bounds", i);
+        int max_hits = 0;
+        for (int l = r[2]; l < r[3]; l++) {
+            int k = d.leaf_kind[l];
+            max_hits += (k == RTC_PLANE || k == RTC_TRIANGLE) ? 1 : ((k == RTC_SPHERE || k == RTC_CUBE) ? 2 : 4);
+        }
+        if (max_hits > RTC_MAX_CSG_HITS)
+            return fail(RTC_ERR_LIMIT, "CSG root %d can produce %d hits per ray, limit %d", i, max_hits, RTC_MAX_CSG_HITS);
+    }
+    for (int i = 0; i < d.n_csg_nodes; i++) {
+        const int32_t* c = d.csg_node + 5 * i;
+        if (c[0] < 0 || c[0] > 2 || c[1] > c[2] || c[2] > c[3] || c[1] < 0 || c[3] > d.n_leaves || c[4] < 0 || c[4] >= d.n_xforms)
+            return fail(RTC_ERR_INVALID, "CSG node %d malformed", i);
+    }
+    for (int i = 0; i < d.n_materials; i++)
+        if (d.mat_program[i] >= d.n_programs) return fail(RTC_ERR_INVALID, "material %d: program out of range", i);
+    for (int i = 0; i < d.n_programs; i++) {
+        if (d.prog_off[i] < 0 || d.prog_len[i] < 1 || d.prog_off[i] + d.prog_len[i] > d.n_instr)
+            return fail(RTC_ERR_INVALID, "pattern program %d out of range", i);
+        int sp = 0, peak = 0;
+        for (int k = d.prog_off[i]; k < d.prog_off[i] + d.prog_len[i]; k++) {
+            int op = d.instr[2 * k], node = d.instr[2 * k + 1];
+            if (op == RTC_OP_BLEND) { sp -= 1; }
+            else if (op == RTC_OP_EVAL || op == RTC_OP_EVAL_AB) {
+                if (node < 0 || node >= d.n_pat_nodes) return fail(RTC_ERR_INVALID, "pattern program %d: node out of range", i);
+                int t = d.pat_type[node];
+                bool known = (t >= RTC_PAT_TEST && t <= RTC_PAT_STRIPE) || (t >= RTC_PAT_MAP_PLANAR && t <= RTC_PAT_MAP_CUBE);
+                if (!known) return fail(RTC_ERR_UNSUPPORTED, "pattern program %d: node type %d cannot be evaluated at a point", i, t);
+                int nch = t == RTC_PAT_MAP_CUBE ? 6 : (t == RTC_PAT_MAP_CYLINDRICAL ? 2 : (t >= RTC_PAT_MAP_PLANAR ? 1 : 0));
+                for (int q = 0; q < nch; q++) {
+                    int ch = d.pat_child[6 * node + q];
+                    if (ch < 0 || ch >= d.n_pat_nodes) return fail(RTC_ERR_INVALID, "pattern node %d: uv child out of range", node);
+                    int ct = d.pat_type[ch];
+                    if (ct < RTC_UV_CHECKER || ct > RTC_UV_IMAGE) return fail(RTC_ERR_INVALID, "pattern node %d: child is not a uv pattern", node);
+                    if (ct == RTC_UV_IMAGE && (d.pat_tex[ch] < 0 || d.pat_tex[ch] >= d.n_textures))
+                        return fail(RTC_ERR_INVALID, "pattern node %d: texture out of range", ch);
+                }
+                sp += (op == RTC_OP_EVAL) ? 1 : -1;
+            } else return fail(RTC_ERR_INVALID, "pattern program %d: unknown opcode %d", i, op);
+            if (sp < 1) return fail(RTC_ERR_INVALID, "pattern program %d underflows its stack", i);
+            peak = std::max(peak, sp);
+        }
+        if (sp != 1) return fail(RTC_ERR_INVALID, "pattern program %d leaves %d values", i, sp);
+        if (peak > RTC_PAT_STACK) return fail(RTC_ERR_LIMIT, "pattern program %d needs a stack of %d, limit %d", i, peak, RTC_PAT_STACK);
+    }
+    for (int i = 0; i < d.n_textures; i++)
+        if (d.tex_w[i] < 1 || d.tex_h[i] < 1 || d.tex_off[i] < 0 || d.tex_off[i] + 3LL * d.tex_w[i] * d.tex_h[i] > d.tex_bytes)
+            return fail(RTC_ERR_INVALID, "texture %d out of range", i);
+    for (int i = 0; i < d.n_lights; i++)
+        if (d.light_type[i] == 1 && (d.light_steps[3 * i] < 1 || d.light_steps[3 * i + 1] < 1))
+            return fail(RTC_ERR_INVALID, "area light %d: steps must be >= 1", i);
+    return 0;
+}
+
+int create_impl(const rtc_scene_desc& d, rtc_scene* sc) {
+    // ---- BVH over the bounded items (host) ----
+    std::vector<rtc::Aabb> boxes((size_t)d.n_items);
+    for (int i = 0; i < d.n_items; i++)
+        for (int k = 0; k < 3; k++) { boxes[i].lo[k] = d.item_lo[3 * i + k]; boxes[i].hi[k] = d.item_hi[3 * i + k]; }
+    rtc::Bvh bvh = rtc::build_bvh(boxes, 4, RTC_BVH_STACK - 2);
+    if (bvh.depth > RTC_BVH_STACK - 1) return fail(RTC_ERR_LIMIT, "BVH depth %d exceeds traversal stack", bvh.depth);
+    sc->bvh_nodes = bvh.n_nodes(); sc->bvh_depth = bvh.depth; sc->bvh_max_leaf = bvh.max_leaf;
+    std::vector<int32_t> prims((size_t)d.n_items);
+    for (int i = 0; i < d.n_items; i++) prims[i] = d.item_prim[bvh.order[i]];
+
+    // ---- precision-independent arrays (uploaded once, shared by both DScene views) ----
+    rtc::DScene<double>& S = sc->d64;
+    memset(&sc->d64, 0, sizeof(sc->d64));
+    memset(&sc->d32, 0, sizeof(sc->d32));
+    DeviceArena& A = sc->shared;
+#define UP(field, src, count) do { if (int rc_ = A.upload((src), (size_t)(count), &S.field)) return rc_; } while (0)
+    UP(leaf_kind, d.leaf_kind, d.n_leaves);
+    UP(leaf_xform, d.leaf_xform, d.n_leaves);
+    UP(leaf_material, d.leaf_material, d.n_leaves);
+    UP(leaf_tri, d.leaf_tri, d.n_leaves);
+    UP(leaf_closed, d.leaf_closed, d.n_leaves);
+    UP(tri_leaf, d.tri_leaf, d.n_tris);
+    UP(node_child, bvh.child.data(), bvh.child.size());
+    UP(bvh_prims, prims.data(), prims.size());
+    UP(unbounded_prims, d.unbounded_prim, d.n_unbounded);
+    UP(csg_root, d.csg_root, 4 * (size_t)d.n_csg_roots);
+    UP(csg_node, d.csg_node, 5 * (size_t)d.n_csg_nodes);
+    UP(mat_shadow, d.mat_shadow, d.n_materials);
+    UP(mat_program, d.mat_program, d.n_materials);
+    UP(pat_type, d.pat_type, d.n_pat_nodes);
+    UP(pat_child, d.pat_child, 6 * (size_t)d.n_pat_nodes);
+    UP(pat_tex, d.pat_tex, d.n_pat_nodes);
+    UP(prog_off, d.prog_off, d.n_programs);
+    UP(prog_len, d.prog_len, d.n_programs);
+    UP(instr, d.instr, 2 * (size_t)d.n_instr);
+    UP(tex_off, d.tex_off, d.n_textures);
+    UP(tex_w, d.tex_w, d.n_textures);
+    UP(tex_h, d.tex_h, d.n_textures);
+    UP(tex_data, d.tex_data, (size_t)d.tex_bytes);
+    UP(light_type, d.light_type, d.n_lights);
+    UP(light_steps, d.light_steps, 3 * (size_t)d.n_lights);
+#undef UP
+    S.n_leaves = d.n_leaves;
+    S.n_bvh_nodes = bvh.n_nodes();
+    S.n_unbounded = d.n_unbounded;
+    S.n_lights = d.n_lights;
+
+    rtc::DScene<float>& F = sc->d32;
+#define CP(field) F.field = S.field
+    CP(n_leaves); CP(leaf_kind); CP(leaf_xform); CP(leaf_material); CP(leaf_tri); CP(leaf_closed); CP(tri_leaf);
+    CP(n_bvh_nodes); CP(node_child); CP(bvh_prims); CP(n_unbounded); CP(unbounded_prims); CP(csg_root); CP(csg_node);
+    CP(mat_shadow); CP(mat_program); CP(pat_type); CP(pat_child); CP(pat_tex); CP(prog_off); CP(prog_len); CP(instr);
+    CP(tex_off); CP(tex_w); CP(tex_h); CP(tex_data); CP(n_lights); CP(light_type); CP(light_steps);
+#undef CP
+    if (int rc = upload_real<double>(d, bvh.box, sc->mem64, sc->d64)) return rc;
+    if (int rc = upload_real<float>(d, bvh.box, sc->mem32, sc->d32)) return rc;
+    for (int i = 0; i < d.n_lights; i++) if (d.light_type[i] == 1 && d.light_steps[3 * i + 2]) sc->has_jitter = true;
+    return 0;
+}
+
+template <class R> rtc::DCamera<R> make_camera(const rtc_camera& c) {
+    rtc::DCamera<R> o;
+    o.hsize = c.hsize; o.vsize = c.vsize;
+    o.half_width = (R)c.half_width; o.half_height = (R)c.half_height; o.pixel_size = (R)c.pixel_size;
+    for (int i = 0; i < 12; i++) o.inv[i] = (R)c.inv_transform[i];
+    return o;
+}
+
+int check_render_args(const rtc_scene* scene, const rtc_camera* cam, const rtc_render_opts* opts, int* tile_size, int* precision,
+                      int* depth, double* eps) {
+    if (!scene || !cam) return fail(RTC_ERR_INVALID, "null scene or camera");
+    if (cam->hsize < 1 || cam->vsize < 1 || (long long)cam->hsize * cam->vsize > (1LL << 30))
+        return fail(RTC_ERR_INVALID, "bad image size %d x %d", cam->hsize, cam->vsize);
+    *precision = opts ? opts->precision : 64;
+    if (*precision == 0) *precision = 64;
+    if (*precision != 64 && *precision != 32) return fail(RTC_ERR_INVALID, "precision must be 64 or 32, got %d", *precision);
+    *depth = opts ? opts->max_depth : 5;
+    if (*depth < 0 || *depth > RTC_MAX_BOUNCE_STACK - 2) return fail(RTC_ERR_LIMIT, "max_depth %d outside 0..%d", *depth, RTC_MAX_BOUNCE_STACK - 2);
+    *tile_size = (opts && opts->tile_size) ? opts->tile_size : 32;
+    if (*tile_size < 8 || *tile_size % 8 || *tile_size > 1024) return fail(RTC_ERR_INVALID, "tile_size must be a multiple of 8 in 8..1024");
+    *eps = (opts && opts->shade_eps > 0) ? opts->shade_eps : (*precision == 64 ? 0.000001 : 0.0002);
+    return 0;
+}
+
+int launch(rtc_scene* scene, const rtc_camera* cam, const rtc_render_opts* opts, int32_t n_tiles, const int32_t* tile_ids_dev,
+           double* rgb_dev, int32_t* hit_id_dev, int64_t* rays_dev, hipStream_t stream) {
+    int T, precision, depth;
+    double eps;
+    if (int rc = check_render_args(scene, cam, opts, &T, &precision, &depth, &eps)) return rc;
+    if (!rgb_dev) return fail(RTC_ERR_INVALID, "null output buffer");
+    int tiles_x = (cam->hsize + T - 1) / T, tiles_y = (cam->vsize + T - 1) / T;
+    if (!tile_ids_dev) n_tiles = tiles_x * tiles_y;
+    if (n_tiles < 0) return fail(RTC_ERR_INVALID, "negative tile count");
+    if (n_tiles == 0) return 0;
+    HIP_TRY(hipSetDevice(scene->device));
+    rtc::DFrame F;
+    F.n_tiles = n_tiles; F.tile_size = T; F.tiles_x = tiles_x; F.tile_ids = tile_ids_dev;
+    F.rgb = rgb_dev; F.hit_id = hit_id_dev; F.rays = reinterpret_cast<unsigned long long*>(rays_dev);
+    F.max_depth = depth; F.seed = opts ? opts->seed : 0;
+    long long work = (long long)n_tiles * T * T;
+    long long blocks = (work + RTC_BLOCK - 1) / RTC_BLOCK;
+    if (blocks > 0x7FFFFFFFLL) return fail(RTC_ERR_LIMIT, "too many blocks");
+    if (precision == 64)
+        hipLaunchKernelGGL(trace_kernel<double>, dim3((unsigned)blocks), dim3(RTC_BLOCK), 0, stream, scene->d64,
+                           make_camera<double>(*cam), F, eps);
+    else
+        hipLaunchKernelGGL(trace_kernel<float>, dim3((unsigned)blocks), dim3(RTC_BLOCK), 0, stream, scene->d32,
+                           make_camera<float>(*cam), F, (float)eps);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// host-buffer path shared by rtc_render and rtc_render_tiles
+int render_host(rtc_scene* scene, const rtc_camera* cam, const rtc_render_opts* opts, int32_t n_tiles, const int32_t* tile_ids,
+                bool tiled, double* rgb_out, int32_t* hit_id_out, rtc_stats* stats_out) {
+    int T, precision, depth;
+    double eps;
+    if (int rc = check_render_args(scene, cam, opts, &T, &precision, &depth, &eps)) return rc;
+    if (!rgb_out) return fail(RTC_ERR_INVALID, "null rgb_out");
+    if (tiled && (n_tiles < 0 || (n_tiles > 0 && !tile_ids))) return fail(RTC_ERR_INVALID, "bad tile list");
+    int tiles_x = (cam->hsize + T - 1) / T, tiles_y = (cam->vsize + T - 1) / T;
+    if (tiled)
+        for (int i = 0; i < n_tiles; i++)
+            if (tile_ids[i] < 0 || tile_ids[i] >= tiles_x * tiles_y) return fail(RTC_ERR_INVALID, "tile id %d out of range", tile_ids[i]);
+    size_t n_px = tiled ? (size_t)n_tiles * T * T : (size_t)cam->hsize * cam->vsize;
+    if (stats_out) memset(stats_out, 0, sizeof(*stats_out));
+    if (n_px == 0) return 0;
+    HIP_TRY(hipSetDevice(scene->device));
+    double* d_rgb = nullptr; int32_t* d_id = nullptr; int64_t* d_rays = nullptr; int32_t* d_tiles = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int rc = 0;
+    auto cleanup = [&]() {
+        if (d_rgb) (void)hipFree(d_rgb);
+        if (d_id) (void)hipFree(d_id);
+        if (d_rays) (void)hipFree(d_rays);
+        if (d_tiles) (void)hipFree(d_tiles);
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+    };
+#define TRY_C(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { rc = fail(RTC_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); cleanup(); return rc; } } while (0)
+    TRY_C(hipMalloc(&d_rgb, n_px * 3 * sizeof(double)));
+    if (tiled) TRY_C(hipMemset(d_rgb, 0, n_px * 3 * sizeof(double)));
+    if (hit_id_out) { TRY_C(hipMalloc(&d_id, n_px * sizeof(int32_t))); TRY_C(hipMemset(d_id, 0xFF, n_px * sizeof(int32_t))); }
+    TRY_C(hipMalloc(&d_rays, 4 * sizeof(int64_t)));
+    TRY_C(hipMemset(d_rays, 0, 4 * sizeof(int64_t)));
+    if (tiled) {
+        TRY_C(hipMalloc(&d_tiles, (size_t)n_tiles * sizeof(int32_t)));
+        TRY_C(hipMemcpy(d_tiles, tile_ids, (size_t)n_tiles * sizeof(int32_t), hipMemcpyHostToDevice));
+    }
+    TRY_C(hipEventCreate(&e0));
+    TRY_C(hipEventCreate(&e1));
+    TRY_C(hipEventRecord(e0, nullptr));
+    rc = launch(scene, cam, opts, n_tiles, d_tiles, d_rgb, d_id, d_rays, nullptr);
+    if (rc) { cleanup(); return rc; }
+    TRY_C(hipEventRecord(e1, nullptr));
+    TRY_C(hipEventSynchronize(e1));
+    float ms = 0;
+    TRY_C(hipEventElapsedTime(&ms, e0, e1));
+    TRY_C(hipMemcpy(rgb_out, d_rgb, n_px * 3 * sizeof(double), hipMemcpyDeviceToHost));
+    if (hit_id_out) TRY_C(hipMemcpy(hit_id_out, d_id, n_px * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (stats_out) {
+        TRY_C(hipMemcpy(stats_out->rays, d_rays, 4 * sizeof(int64_t), hipMemcpyDeviceToHost));
+        stats_out->kernel_ms = ms;
+    }
+#undef TRY_C
+    cleanup();
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rtc_version(void) { return RTC_VERSION; }
+
+int rtc_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
+
+const char* rtc_last_error(void) { return g_err.c_str(); }
+
+int rtc_scene_create(const rtc_scene_desc* desc, int device, rtc_scene** out) {
+    if (!desc || !out) return fail(RTC_ERR_INVALID, "null argument");
+    *out = nullptr;
+    if (int rc = validate(*desc)) return rc;
+    int n = rtc_device_count();
+    if (n <= 0) return fail(RTC_ERR_NO_DEVICE, "no GPU visible to HIP");
+    if (device < 0 || device >= n) return fail(RTC_ERR_NO_DEVICE, "device %d out of range (%d visible)", device, n);
+    HIP_TRY(hipSetDevice(device));
+    rtc_scene* sc = new rtc_scene();
+    sc->device = device;
+    sc->n_leaves = desc->n_leaves;
+    int rc = create_impl(*desc, sc);
+    if (rc) { rtc_scene_destroy(sc); return rc; }
+    *out = sc;
+    return 0;
+}
+
+void rtc_scene_destroy(rtc_scene* scene) {
+    if (!scene) return;
+    (void)hipSetDevice(scene->device);
+    scene->shared.release(); scene->mem64.release(); scene->mem32.release();
+    delete scene;
+}
+
+int rtc_scene_get_info(const rtc_scene* scene, rtc_scene_info* out) {
+    if (!scene || !out) return fail(RTC_ERR_INVALID, "null argument");
+    out->device = scene->device;
+    out->bvh_nodes = scene->bvh_nodes; out->bvh_depth = scene->bvh_depth; out->bvh_max_leaf = scene->bvh_max_leaf;
+    out->device_bytes_fp64 = (int64_t)(scene->shared.bytes + scene->mem64.bytes);
+    out->device_bytes_fp32 = (int64_t)(scene->shared.bytes + scene->mem32.bytes);
+    return 0;
+}
+
+int rtc_render(rtc_scene* scene, const rtc_camera* cam, const rtc_render_opts* opts, double* rgb_out, int32_t* hit_id_out,
+               rtc_stats* stats_out) {
+    return render_host(scene, cam, opts, 0, nullptr, false, rgb_out, hit_id_out, stats_out);
+}
+
+int rtc_render_tiles(rtc_scene* scene, const rtc_camera* cam, const rtc_render_opts* opts, int32_t n_tiles, const int32_t* tile_ids,
+                     double* rgb_out, int32_t* hit_id_out, rtc_stats* stats_out) {
+    return render_host(scene, cam, opts, n_tiles, tile_ids, true, rgb_out, hit_id_out, stats_out);
+}
+
+int rtc_render_device(rtc_scene* scene, const rtc_camera* cam, const rtc_render_opts* opts, int32_t n_tiles, const int32_t* tile_ids_dev,
+                      double* rgb_dev, int32_t* hit_id_dev, int64_t* rays_dev, void* stream) {
+    return launch(scene, cam, opts, n_tiles, tile_ids_dev, rgb_dev, hit_id_dev, rays_dev, static_cast<hipStream_t>(stream));
+}
+
+int rtc_quantize_device(const double* rgb_dev, int32_t hsize, int32_t vsize, double max_component, uint8_t* out_dev, void* stream) {
+    if (!rgb_dev || !out_dev || hsize < 1 || vsize < 1) return fail(RTC_ERR_INVALID, "bad argument");
+    long long n = (long long)hsize * vsize * 3;
+    hipLaunchKernelGGL(quantize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), rgb_dev, hsize,
+                       vsize, max_component, out_dev);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+}  // extern "C"

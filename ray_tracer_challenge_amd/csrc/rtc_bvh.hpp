@@ -1,0 +1,180 @@
+// rtc_bvh.hpp -- host-side AABB BVH builder (binned SAH, median fallback).
+//
+// Replaces nothing in the reference's results: its Group.local_intersect tests every child
+// regardless of bounds (shapes.py:454), so any conservative hierarchy over the leaves returns
+// the same hit lists.  What it does replace is the role Group.divide (shapes.py:480-507) was
+// written for.  Built once per scene on the host, over the world-space boxes the scene
+// compiler supplies; output is the linear two-children-per-node layout rtc_device.hpp walks.
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <limits>
+#include <vector>
+
+namespace rtc {
+
+struct Aabb {
+    double lo[3], hi[3];
+    void reset() { for (int k = 0; k < 3; k++) { lo[k] = std::numeric_limits<double>::infinity(); hi[k] = -lo[k]; } }
+    void grow(const Aabb& o) { for (int k = 0; k < 3; k++) { lo[k] = std::min(lo[k], o.lo[k]); hi[k] = std::max(hi[k], o.hi[k]); } }
+    double area() const {
+        double d[3] = {hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2]};
+        if (d[0] < 0 || d[1] < 0 || d[2] < 0) return 0;
+        return 2 * (d[0] * d[1] + d[1] * d[2] + d[2] * d[0]);
+    }
+};
+
+struct Bvh {
+    std::vector<double> box;        // [n_nodes][12] child0 lo,hi, child1 lo,hi
+    std::vector<int32_t> child;     // [n_nodes][2]
+    std::vector<int32_t> order;     // item indices in leaf order
+    int depth = 0, max_leaf = 0;
+    int n_nodes() const { return (int)(child.size() / 2); }
+};
+
+class BvhBuilder {
+public:
+    static const int32_t EMPTY = INT32_MIN;
+    BvhBuilder(const std::vector<Aabb>& boxes, int max_leaf, bool median_only)
+        : b_(boxes), max_leaf_(max_leaf), median_(median_only) {}
+
+    Bvh build() {
+        Bvh out;
+        int n = (int)b_.size();
+        idx_.resize(n);
+        for (int i = 0; i < n; i++) idx_[i] = i;
+        cen_.resize(3 * (size_t)n);
+        for (int i = 0; i < n; i++)
+            for (int k = 0; k < 3; k++) cen_[3 * (size_t)i + k] = 0.5 * (b_[i].lo[k] + b_[i].hi[k]);
+        out_ = &out;
+        if (n == 0) return out;
+        if (n <= max_leaf_) {   // a single leaf: node 0 with one child
+            int node = new_node();
+            Aabb bb = bounds(0, n);
+            set_child(node, 0, leaf_code(0, n), bb);
+            Aabb e; e.reset();
+            set_child(node, 1, EMPTY, e);
+            out.depth = 1;
+            out.max_leaf = n;
+        } else {
+            Aabb bb;
+            split(0, n, 1, bb);
+        }
+        out.order = idx_;
+        return out;
+    }
+
+private:
+    const std::vector<Aabb>& b_;
+    int max_leaf_;
+    bool median_;
+    std::vector<int32_t> idx_;
+    std::vector<double> cen_;
+    Bvh* out_ = nullptr;
+
+    static int32_t leaf_code(int first, int count) { return ~((first << 4) | (count - 1)); }
+    int new_node() {
+        out_->box.resize(out_->box.size() + 12);
+        out_->child.resize(out_->child.size() + 2);
+        return out_->n_nodes() - 1;
+    }
+    void set_child(int node, int k, int32_t ref, const Aabb& bb) {
+        double* p = out_->box.data() + 12 * (size_t)node + 6 * k;
+        for (int a = 0; a < 3; a++) { p[a] = bb.lo[a]; p[3 + a] = bb.hi[a]; }
+        out_->child[2 * (size_t)node + k] = ref;
+    }
+    Aabb bounds(int lo, int hi) const {
+        Aabb bb; bb.reset();
+        for (int i = lo; i < hi; i++) bb.grow(b_[idx_[i]]);
+        return bb;
+    }
+
+    // builds the inner node for items [lo, hi) (hi - lo > max_leaf) and returns its index
+    int split(int lo, int hi, int depth, Aabb& bb_out) {
+        int node = new_node();
+        out_->depth = std::max(out_->depth, depth);
+        int n = hi - lo;
+        Aabb cb; cb.reset();
+        for (int i = lo; i < hi; i++)
+            for (int k = 0; k < 3; k++) {
+                double c = cen_[3 * (size_t)idx_[i] + k];
+                cb.lo[k] = std::min(cb.lo[k], c); cb.hi[k] = std::max(cb.hi[k], c);
+            }
+        int axis = 0;
+        for (int k = 1; k < 3; k++) if (cb.hi[k] - cb.lo[k] > cb.hi[axis] - cb.lo[axis]) axis = k;
+        int mid = -1;
+        if (!median_ && cb.hi[axis] > cb.lo[axis]) {
+            const int NB = 16;
+            int best_axis = -1, best_bin = -1;
+            double best_cost = std::numeric_limits<double>::infinity();
+            for (int ax = 0; ax < 3; ax++) {
+                double ext = cb.hi[ax] - cb.lo[ax];
+                if (!(ext > 0)) continue;
+                Aabb bins[NB]; int cnt[NB];
+                for (int q = 0; q < NB; q++) { bins[q].reset(); cnt[q] = 0; }
+                double scale = NB / ext;
+                for (int i = lo; i < hi; i++) {
+                    int q = (int)((cen_[3 * (size_t)idx_[i] + ax] - cb.lo[ax]) * scale);
+                    q = std::min(std::max(q, 0), NB - 1);
+                    bins[q].grow(b_[idx_[i]]); cnt[q]++;
+                }
+                double right_area[NB]; int right_cnt[NB];
+                Aabb acc; acc.reset(); int c = 0;
+                for (int q = NB - 1; q > 0; q--) { acc.grow(bins[q]); c += cnt[q]; right_area[q] = acc.area(); right_cnt[q] = c; }
+                acc.reset(); c = 0;
+                for (int q = 0; q < NB - 1; q++) {
+                    acc.grow(bins[q]); c += cnt[q];
+                    if (c == 0 || right_cnt[q + 1] == 0) continue;
+                    double cost = acc.area() * c + right_area[q + 1] * right_cnt[q + 1];
+                    if (cost < best_cost) { best_cost = cost; best_axis = ax; best_bin = q; }
+                }
+            }
+            if (best_axis >= 0) {
+                double ext = cb.hi[best_axis] - cb.lo[best_axis], scale = NB / ext, base = cb.lo[best_axis];
+                int ax = best_axis, bb = best_bin;
+                auto it = std::partition(idx_.begin() + lo, idx_.begin() + hi, [&](int32_t i) {
+                    int q = (int)((cen_[3 * (size_t)i + ax] - base) * scale);
+                    q = std::min(std::max(q, 0), NB - 1);
+                    return q <= bb;
+                });
+                mid = (int)(it - idx_.begin());
+                if (mid == lo || mid == hi) mid = -1;
+            }
+        }
+        if (mid < 0) {   // median split on the widest centroid axis (also the degenerate-SAH fallback)
+            mid = lo + n / 2;
+            int ax = axis;
+            std::nth_element(idx_.begin() + lo, idx_.begin() + mid, idx_.begin() + hi, [&](int32_t a, int32_t b) {
+                double ca = cen_[3 * (size_t)a + ax], cb2 = cen_[3 * (size_t)b + ax];
+                return ca < cb2 || (ca == cb2 && a < b);
+            });
+        }
+        int range[2][2] = {{lo, mid}, {mid, hi}};
+        bb_out.reset();
+        for (int k = 0; k < 2; k++) {
+            int a = range[k][0], b = range[k][1];
+            Aabb bb;
+            int32_t ref;
+            if (b - a <= max_leaf_) {
+                bb = bounds(a, b);
+                ref = leaf_code(a, b - a);
+                out_->max_leaf = std::max(out_->max_leaf, b - a);
+                out_->depth = std::max(out_->depth, depth);
+            } else {
+                ref = split(a, b, depth + 1, bb);
+            }
+            set_child(node, k, ref, bb);
+            bb_out.grow(bb);
+        }
+        return node;
+    }
+};
+
+inline Bvh build_bvh(const std::vector<Aabb>& boxes, int max_leaf, int max_depth) {
+    Bvh b = BvhBuilder(boxes, max_leaf, false).build();
+    if (b.depth > max_depth) b = BvhBuilder(boxes, max_leaf, true).build();
+    return b;
+}
+
+}  // namespace rtc

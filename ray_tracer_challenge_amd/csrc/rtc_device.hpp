@@ -1,0 +1,788 @@
+// rtc_device.hpp -- device side of the MI355X trace loop (gfx950, wave64).
+//
+// Everything the reference does per ray in Python lives here as inlined device functions,
+// templated on the arithmetic type R (double = the reference's fp64, float = throughput mode).
+// Citations are reference file:line.  Differences from the reference's *structure* (none of
+// them change a hit list):
+//   * one collapsed world->object 3x4 per leaf instead of an inverse per tree level;
+//   * triangles are pre-transformed to world space (their det-epsilon is rescaled to match);
+//   * a BVH over world-space AABBs replaces "every leaf for every ray" (shapes.py:454);
+//   * nearest-hit / any-hit queries replace full sorted hit lists; the refraction container
+//     walk (renderer.py:224-242) is a second, order-free pass over the line's leaves;
+//   * recursion (renderer.py:400-406, 336-353) is an explicit per-lane stack.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/rtc_api.h"
+
+#define RTC_BLOCK 256
+#define RTC_BVH_STACK 32      // per-lane traversal stack entries, in LDS
+#define RTC_MAX_CSG_HITS 32   // hits gathered per CSG root per ray
+#define RTC_MAX_BOUNCE_STACK 8
+#define RTC_PAT_STACK 6
+#define RTC_EMPTY_CHILD INT32_MIN
+
+namespace rtc {
+
+template <class R> struct V3 { R x, y, z; };
+template <class R> __device__ __forceinline__ V3<R> mk(R x, R y, R z) { V3<R> v = {x, y, z}; return v; }
+template <class R> __device__ __forceinline__ V3<R> operator+(V3<R> a, V3<R> b) { return mk<R>(a.x + b.x, a.y + b.y, a.z + b.z); }
+template <class R> __device__ __forceinline__ V3<R> operator-(V3<R> a, V3<R> b) { return mk<R>(a.x - b.x, a.y - b.y, a.z - b.z); }
+template <class R> __device__ __forceinline__ V3<R> operator*(V3<R> a, R s) { return mk<R>(a.x * s, a.y * s, a.z * s); }
+template <class R> __device__ __forceinline__ V3<R> operator*(V3<R> a, V3<R> b) { return mk<R>(a.x * b.x, a.y * b.y, a.z * b.z); }
+template <class R> __device__ __forceinline__ V3<R> neg(V3<R> a) { return mk<R>(-a.x, -a.y, -a.z); }
+template <class R> __device__ __forceinline__ R dot(V3<R> a, V3<R> b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+template <class R> __device__ __forceinline__ V3<R> cross(V3<R> a, V3<R> b) {
+    return mk<R>(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+__device__ __forceinline__ float rsqrt_(float x) { return 1.0f / sqrtf(x); }
+__device__ __forceinline__ double rsqrt_(double x) { return 1.0 / sqrt(x); }
+__device__ __forceinline__ float sqrt_(float x) { return sqrtf(x); }
+__device__ __forceinline__ double sqrt_(double x) { return sqrt(x); }
+__device__ __forceinline__ float abs_(float x) { return fabsf(x); }
+__device__ __forceinline__ double abs_(double x) { return fabs(x); }
+__device__ __forceinline__ float floor_(float x) { return floorf(x); }
+__device__ __forceinline__ double floor_(double x) { return floor(x); }
+__device__ __forceinline__ float pow_(float x, float y) { return powf(x, y); }
+__device__ __forceinline__ double pow_(double x, double y) { return pow(x, y); }
+__device__ __forceinline__ float atan2_(float y, float x) { return atan2f(y, x); }
+__device__ __forceinline__ double atan2_(double y, double x) { return atan2(y, x); }
+__device__ __forceinline__ float acos_(float x) { return acosf(x); }
+__device__ __forceinline__ double acos_(double x) { return acos(x); }
+__device__ __forceinline__ float fmod_(float x, float y) { return fmodf(x, y); }
+__device__ __forceinline__ double fmod_(double x, double y) { return fmod(x, y); }
+__device__ __forceinline__ float rint_(float x) { return rintf(x); }
+__device__ __forceinline__ double rint_(double x) { return rint(x); }
+__device__ __forceinline__ float min_(float a, float b) { return fminf(a, b); }
+__device__ __forceinline__ double min_(double a, double b) { return fmin(a, b); }
+__device__ __forceinline__ float max_(float a, float b) { return fmaxf(a, b); }
+__device__ __forceinline__ double max_(double a, double b) { return fmax(a, b); }
+template <class R> __device__ __forceinline__ R inf_() { return (R)__builtin_huge_val(); }
+
+// vector.py:170 normalize = v * (1 / |v|)
+template <class R> __device__ __forceinline__ V3<R> normalize(V3<R> a) { return a * (R(1) / sqrt_(dot(a, a))); }
+// renderer.py:893
+template <class R> __device__ __forceinline__ V3<R> reflect(V3<R> in, V3<R> n) { return in - n * (R(2) * dot(in, n)); }
+// np.isclose(a, b), rtol 1e-5, atol 1e-8
+template <class R> __device__ __forceinline__ bool isclose(R a, R b) { return abs_(a - b) <= R(1e-8) + R(1e-5) * abs_(b); }
+// numpy / Python floor-mod
+template <class R> __device__ __forceinline__ R pymod(R a, R b) {
+    R m = fmod_(a, b);
+    if (m != R(0)) { if ((b < R(0)) != (m < R(0))) m += b; } else m = R(0);
+    return m;
+}
+// Python max(a,b,c)/min(a,b,c) comparison chains (NaN of 0*inf survives in first position)
+template <class R> __device__ __forceinline__ R pymax3(R a, R b, R c) { R m = a; if (b > m) m = b; if (c > m) m = c; return m; }
+template <class R> __device__ __forceinline__ R pymin3(R a, R b, R c) { R m = a; if (b < m) m = b; if (c < m) m = c; return m; }
+
+template <class R> struct Ray { V3<R> o, d; };
+
+template <class R> __device__ __forceinline__ V3<R> xpoint(const R* __restrict__ m, V3<R> p) {
+    return mk<R>(m[0] * p.x + m[1] * p.y + m[2] * p.z + m[3], m[4] * p.x + m[5] * p.y + m[6] * p.z + m[7],
+                 m[8] * p.x + m[9] * p.y + m[10] * p.z + m[11]);
+}
+template <class R> __device__ __forceinline__ V3<R> xvector(const R* __restrict__ m, V3<R> p) {
+    return mk<R>(m[0] * p.x + m[1] * p.y + m[2] * p.z, m[4] * p.x + m[5] * p.y + m[6] * p.z,
+                 m[8] * p.x + m[9] * p.y + m[10] * p.z);
+}
+template <class R> __device__ __forceinline__ V3<R> xtvector(const R* __restrict__ m, V3<R> p) {
+    return mk<R>(m[0] * p.x + m[4] * p.y + m[8] * p.z, m[1] * p.x + m[5] * p.y + m[9] * p.z,
+                 m[2] * p.x + m[6] * p.y + m[10] * p.z);
+}
+
+// ------------------------------------------------------------------------------------------
+// device scene (struct of device pointers; one instance per precision)
+// ------------------------------------------------------------------------------------------
+template <class R> struct DScene {
+    int32_t n_leaves;
+    const int32_t* leaf_kind; const int32_t* leaf_xform; const int32_t* leaf_material;
+    const int32_t* leaf_tri; const int32_t* leaf_closed; const R* leaf_minmax;
+    const R* xform;
+    const R* tri_geom; const R* tri_norm; const int32_t* tri_leaf;
+    int32_t n_bvh_nodes;           // 0 = no bounded items
+    const R* node_box;             // [n][12] child0 lo,hi, child1 lo,hi
+    const int32_t* node_child;     // [n][2]  >=0 inner node; <0: ~c = first<<4 | (count-1); RTC_EMPTY_CHILD = none
+    const int32_t* bvh_prims;      // prim codes in BVH leaf order
+    int32_t n_unbounded; const int32_t* unbounded_prims;
+    const int32_t* csg_root; const int32_t* csg_node; const R* csg_bbox;
+    const R* mat; const int32_t* mat_shadow; const int32_t* mat_program;
+    const int32_t* pat_type; const R* pat_inv; const R* pat_ab; const int32_t* pat_child;
+    const R* pat_param; const R* pat_colors; const int32_t* pat_tex;
+    const int32_t* prog_off; const int32_t* prog_len; const int32_t* instr;
+    const int64_t* tex_off; const int32_t* tex_w; const int32_t* tex_h; const R* tex_scale; const uint8_t* tex_data;
+    int32_t n_lights;
+    const int32_t* light_type; const R* light_geom; const int32_t* light_steps; const R* light_intensity;
+};
+
+template <class R> struct DCamera {
+    int32_t hsize, vsize;
+    R half_width, half_height, pixel_size;
+    R inv[12];
+};
+
+struct DFrame {
+    int32_t n_tiles;             // tiles to render
+    int32_t tile_size, tiles_x;
+    const int32_t* tile_ids;     // NULL: tile k = k, output in [x][y][c]; else compact tile layout
+    double* rgb; int32_t* hit_id; unsigned long long* rays;
+    int32_t max_depth;
+    uint64_t seed;
+};
+
+#define RTC_EPS R(0.000001) /* renderer.py:15, shapes.py:8 */
+
+// ------------------------------------------------------------------------------------------
+// local intersections: each returns the number of hits written to t[] (unsorted)
+// ------------------------------------------------------------------------------------------
+// shapes.py:597-618 / 87-108
+template <class R> __device__ __forceinline__ void check_axis(R origin, R direction, R lo, R hi, R& tmin, R& tmax) {
+    R n0 = lo - origin, n1 = hi - origin, a, b;
+    if (abs_(direction) >= RTC_EPS) { a = n0 / direction; b = n1 / direction; }
+    else { a = n0 * inf_<R>(); b = n1 * inf_<R>(); }
+    if (a > b) { tmin = b; tmax = a; } else { tmin = a; tmax = b; }
+}
+template <class R> __device__ __forceinline__ bool box_hit(const Ray<R>& r, const R* lo, const R* hi, R& tmin, R& tmax) {
+    R xa, xb, ya, yb, za, zb;
+    check_axis(r.o.x, r.d.x, lo[0], hi[0], xa, xb);
+    check_axis(r.o.y, r.d.y, lo[1], hi[1], ya, yb);
+    check_axis(r.o.z, r.d.z, lo[2], hi[2], za, zb);
+    tmin = pymax3(xa, ya, za);
+    tmax = pymin3(xb, yb, zb);
+    return !(tmin > tmax);
+}
+// shapes.py:525-535
+template <class R> __device__ __forceinline__ int sphere_hits(const Ray<R>& r, R* t) {
+    R a = dot(r.d, r.d), b = R(2) * dot(r.d, r.o), c = dot(r.o, r.o) - R(1);
+    R disc = b * b - R(4) * a * c;
+    if (disc < R(0)) return 0;
+    R sq = sqrt_(disc);
+    t[0] = (-b - sq) / (R(2) * a);
+    t[1] = (-b + sq) / (R(2) * a);
+    return 2;
+}
+// shapes.py:550-555
+template <class R> __device__ __forceinline__ int plane_hits(const Ray<R>& r, R* t) {
+    if (abs_(r.d.y) < RTC_EPS) return 0;
+    t[0] = -r.o.y / r.d.y;
+    return 1;
+}
+// shapes.py:572-582
+template <class R> __device__ __forceinline__ int cube_hits(const Ray<R>& r, R* t) {
+    const R lo[3] = {R(-1), R(-1), R(-1)}, hi[3] = {R(1), R(1), R(1)};
+    R tmin, tmax;
+    if (!box_hit(r, lo, hi, tmin, tmax)) return 0;
+    t[0] = tmin; t[1] = tmax;
+    return 2;
+}
+// shapes.py:734-792 (cone = false) and 636-705 (cone = true, quirks kept)
+template <class R, bool CONE> __device__ __forceinline__ int quadric_hits(const Ray<R>& r, R minimum, R maximum, bool closed, R* t) {
+    int n = 0;
+    R a = r.d.x * r.d.x + r.d.z * r.d.z;
+    R b = R(2) * r.o.x * r.d.x + R(2) * r.o.z * r.d.z;
+    R c = r.o.x * r.o.x + r.o.z * r.o.z;
+    if (CONE) { a -= r.d.y * r.d.y; b -= R(2) * r.o.y * r.d.y; c -= r.o.y * r.o.y; } else { c -= R(1); }
+    bool a0 = abs_(a) <= R(1e-8);   // np.isclose(a, 0)
+    if (a0) {
+        if (CONE) t[n++] = -c / (R(2) * b);  // even when b ~ 0 (shapes.py:647-650)
+    } else {
+        R disc = b * b - R(4) * a * c;
+        if (disc < R(0)) return 0;
+        R sq = sqrt_(disc);
+        R t0 = (-b - sq) / (R(2) * a), t1 = (-b + sq) / (R(2) * a);
+        if (t0 > t1) { R tmp = t0; t0 = t1; t1 = tmp; }
+        R y0 = r.o.y + t0 * r.d.y;
+        if (minimum < y0 && y0 < maximum) t[n++] = t0;
+        R y1 = r.o.y + t1 * r.d.y;
+        if (minimum < y1 && y1 < maximum) t[n++] = t1;
+    }
+    if (closed && !(abs_(r.d.y) <= R(1e-8))) {
+        R lim[2] = {minimum, maximum};
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            R tc = (lim[k] - r.o.y) / r.d.y;
+            R x = r.o.x + tc * r.d.x, z = r.o.z + tc * r.d.z;
+            R rad = CONE ? abs_(lim[k]) : R(1);   // |y_cap|, not y_cap^2 (shapes.py:689-693)
+            if (!(x * x + z * z > rad)) t[n++] = tc;
+        }
+    }
+    return n;
+}
+// shapes.py:812-830 / 860-878 on world-space data; g = p1, e1, e2, det_eps
+template <class R> __device__ __forceinline__ bool tri_hit(const R* __restrict__ g, const Ray<R>& r, R& t, R& u, R& v) {
+    V3<R> p1 = mk<R>(g[0], g[1], g[2]), e1 = mk<R>(g[3], g[4], g[5]), e2 = mk<R>(g[6], g[7], g[8]);
+    V3<R> dir_cross_e2 = cross(r.d, e2);
+    R det = dot(e1, dir_cross_e2);
+    if (abs_(det) < g[9]) return false;
+    R f = R(1) / det;
+    V3<R> p1_to_origin = r.o - p1;
+    u = f * dot(p1_to_origin, dir_cross_e2);
+    if (u < R(0) || u > R(1)) return false;
+    V3<R> origin_cross_e1 = cross(p1_to_origin, e1);
+    v = f * dot(r.d, origin_cross_e1);
+    if (v < R(0) || (u + v) > R(1)) return false;
+    t = f * dot(e2, origin_cross_e1);
+    return true;
+}
+
+// hits of one leaf (world-space ray in, t's out, unsorted); u,v only for triangles
+template <class R> __device__ __forceinline__ int leaf_hits(const DScene<R>& S, int leaf, const Ray<R>& ray, R* t, R& u, R& v) {
+    int kind = S.leaf_kind[leaf];
+    if (kind == RTC_TRIANGLE) {
+        return tri_hit(S.tri_geom + 12 * (size_t)S.leaf_tri[leaf], ray, t[0], u, v) ? 1 : 0;
+    }
+    const R* m = S.xform + 12 * (size_t)S.leaf_xform[leaf];
+    Ray<R> r = {xpoint(m, ray.o), xvector(m, ray.d)};   // shapes.py:271-273, 1447-1448
+    switch (kind) {
+    case RTC_SPHERE: return sphere_hits(r, t);
+    case RTC_PLANE: return plane_hits(r, t);
+    case RTC_CUBE: return cube_hits(r, t);
+    case RTC_CYLINDER: return quadric_hits<R, false>(r, S.leaf_minmax[2 * leaf], S.leaf_minmax[2 * leaf + 1], S.leaf_closed[leaf] != 0, t);
+    default: return quadric_hits<R, true>(r, S.leaf_minmax[2 * leaf], S.leaf_minmax[2 * leaf + 1], S.leaf_closed[leaf] != 0, t);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// CSG (shapes.py:363-422): hits of all leaves of a root, sorted, then filtered node by node
+// (children before parents, so a parent only sees what its children let through).
+// ------------------------------------------------------------------------------------------
+template <class R> struct CsgHits { R t[RTC_MAX_CSG_HITS]; int leaf[RTC_MAX_CSG_HITS]; int n; };
+
+__device__ __forceinline__ bool csg_allowed(int op, bool lhit, bool inl, bool inr) {
+    if (op == RTC_CSG_UNION) return (lhit && !inr) || (!lhit && !inl);
+    if (op == RTC_CSG_INTERSECT) return (lhit && inr) || (!lhit && inl);
+    return (lhit && !inr) || (!lhit && inl);
+}
+
+template <class R> __device__ __noinline__ void csg_hits(const DScene<R>& S, int root, const Ray<R>& ray, CsgHits<R>& H) {
+    const int32_t* rt = S.csg_root + 4 * root;
+    H.n = 0;
+    for (int leaf = rt[2]; leaf < rt[3]; leaf++) {
+        R t[4], u, v;
+        int n = leaf_hits(S, leaf, ray, t, u, v);
+        for (int k = 0; k < n && H.n < RTC_MAX_CSG_HITS; k++) {   // stable insertion by t
+            int j = H.n++;
+            while (j > 0 && H.t[j - 1] > t[k]) { H.t[j] = H.t[j - 1]; H.leaf[j] = H.leaf[j - 1]; j--; }
+            H.t[j] = t[k]; H.leaf[j] = leaf;
+        }
+    }
+    for (int nd = rt[0]; nd < rt[0] + rt[1]; nd++) {
+        const int32_t* c = S.csg_node + 5 * nd;
+        int op = c[0], l0 = c[1], l1 = c[2], l2 = c[3];
+        const R* m = S.xform + 12 * (size_t)c[4];
+        Ray<R> r = {xpoint(m, ray.o), xvector(m, ray.d)};
+        R tmin, tmax;
+        bool boxed = box_hit(r, S.csg_bbox + 6 * nd, S.csg_bbox + 6 * nd + 3, tmin, tmax);   // shapes.py:367
+        bool inl = false, inr = false;
+        int w = 0;
+        for (int i = 0; i < H.n; i++) {
+            int leaf = H.leaf[i];
+            bool keep = true;
+            if (leaf >= l0 && leaf < l2) {
+                bool lhit = leaf < l1;
+                keep = boxed && csg_allowed(op, lhit, inl, inr);
+                if (lhit) inl = !inl; else inr = !inr;
+            }
+            if (keep) { H.t[w] = H.t[i]; H.leaf[w] = leaf; w++; }
+        }
+        H.n = w;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// queries over the whole scene
+// ------------------------------------------------------------------------------------------
+struct PrimCode {
+    int kind, idx; bool noshadow;
+    __device__ __forceinline__ explicit PrimCode(int32_t c)
+        : kind((int)((uint32_t)c >> 28)), idx((int)((uint32_t)c & 0x07FFFFFFu)), noshadow((((uint32_t)c >> 27) & 1u) != 0) {}
+};
+
+// Visitor V: bool prim(code) -> true = stop the traversal; R limit() = current far bound.
+// Boxes are visited when their slab interval overlaps (tlo, limit()).
+template <class R, class V> __device__ __forceinline__ void traverse(const DScene<R>& S, const Ray<R>& ray, R tlo, V& vis, int* stack /* LDS, stride RTC_BLOCK */) {
+    for (int i = 0; i < S.n_unbounded; i++)
+        if (vis.prim(S.unbounded_prims[i])) return;
+    if (S.n_bvh_nodes == 0) return;
+    V3<R> inv = mk<R>(R(1) / ray.d.x, R(1) / ray.d.y, R(1) / ray.d.z);
+    int sp = 0;
+    int node = 0;
+    while (true) {
+        if (node >= 0) {
+            const R* b = S.node_box + 12 * (size_t)node;
+            int c0 = S.node_child[2 * node], c1 = S.node_child[2 * node + 1];
+            R near[2], far[2];
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                const R* lo = b + 6 * k; const R* hi = lo + 3;
+                R x0 = (lo[0] - ray.o.x) * inv.x, x1 = (hi[0] - ray.o.x) * inv.x;
+                R y0 = (lo[1] - ray.o.y) * inv.y, y1 = (hi[1] - ray.o.y) * inv.y;
+                R z0 = (lo[2] - ray.o.z) * inv.z, z1 = (hi[2] - ray.o.z) * inv.z;
+                // fmin/fmax drop the NaN of 0*inf (origin on a slab plane of a parallel ray): conservative
+                near[k] = max_(max_(min_(x0, x1), min_(y0, y1)), min_(z0, z1));
+                far[k] = min_(min_(max_(x0, x1), max_(y0, y1)), max_(z0, z1));
+            }
+            R lim = vis.limit();
+            bool h0 = c0 != RTC_EMPTY_CHILD && near[0] <= far[0] && far[0] >= tlo && near[0] <= lim;
+            bool h1 = c1 != RTC_EMPTY_CHILD && near[1] <= far[1] && far[1] >= tlo && near[1] <= lim;
+            if (h0 && h1) {
+                bool swap = near[1] < near[0];
+                int first = swap ? c1 : c0, second = swap ? c0 : c1;
+                stack[sp * RTC_BLOCK] = second; sp++;
+                node = first;
+                continue;
+            } else if (h0) { node = c0; continue; }
+            else if (h1) { node = c1; continue; }
+        } else {
+            int code = ~node;
+            int first = code >> 4, count = (code & 15) + 1;
+            for (int i = 0; i < count; i++)
+                if (vis.prim(S.bvh_prims[first + i])) return;
+        }
+        if (sp == 0) return;
+        sp--;
+        node = stack[sp * RTC_BLOCK];
+    }
+}
+
+// hit(intersect_world(ray)) (renderer.py:75-79, shapes.py:1422-1425): smallest t > 0
+template <class R> struct NearestVisitor {
+    const DScene<R>& S; const Ray<R>& ray;
+    R best; int leaf; R u, v;
+    __device__ __forceinline__ NearestVisitor(const DScene<R>& s, const Ray<R>& r) : S(s), ray(r), best(inf_<R>()), leaf(-1), u(0), v(0) {}
+    __device__ __forceinline__ R limit() const { return best; }
+    __device__ __forceinline__ bool prim(int32_t code) {
+        PrimCode p(code);
+        if (p.kind == RTC_TRIANGLE) {
+            R t, tu, tv;
+            if (tri_hit(S.tri_geom + 12 * (size_t)p.idx, ray, t, tu, tv) && t > R(0) && t < best) {
+                best = t; leaf = S.tri_leaf[p.idx]; u = tu; v = tv;
+            }
+        } else if (p.kind == RTC_CSG_ROOT) {
+            CsgHits<R> H;
+            csg_hits(S, p.idx, ray, H);
+            for (int i = 0; i < H.n; i++)
+                if (H.t[i] > R(0)) {
+                    if (H.t[i] < best) {
+                        best = H.t[i]; leaf = H.leaf[i];
+                        if (S.leaf_kind[leaf] == RTC_TRIANGLE) { R t; tri_hit(S.tri_geom + 12 * (size_t)S.leaf_tri[leaf], ray, t, u, v); }
+                    }
+                    break;
+                }
+        } else {
+            R t[4], tu, tv;
+            int n = leaf_hits(S, p.idx, ray, t, tu, tv);
+            for (int k = 0; k < n; k++)
+                if (t[k] > R(0) && t[k] < best) { best = t[k]; leaf = p.idx; }
+        }
+        return false;
+    }
+};
+
+// is_shadowed (renderer.py:552-560): any hit of a shadow-casting leaf with 0 < t < distance
+template <class R> struct ShadowVisitor {
+    const DScene<R>& S; const Ray<R>& ray; R dist; bool shadowed;
+    __device__ __forceinline__ ShadowVisitor(const DScene<R>& s, const Ray<R>& r, R d) : S(s), ray(r), dist(d), shadowed(false) {}
+    __device__ __forceinline__ R limit() const { return dist; }
+    __device__ __forceinline__ bool prim(int32_t code) {
+        PrimCode p(code);
+        if (p.kind == RTC_CSG_ROOT) {
+            CsgHits<R> H;
+            csg_hits(S, p.idx, ray, H);
+            for (int i = 0; i < H.n; i++)
+                if (H.t[i] > R(0) && H.t[i] < dist && S.mat_shadow[S.leaf_material[H.leaf[i]]]) { shadowed = true; return true; }
+            return false;
+        }
+        if (p.noshadow) return false;
+        if (p.kind == RTC_TRIANGLE) {
+            R t, tu, tv;
+            if (tri_hit(S.tri_geom + 12 * (size_t)p.idx, ray, t, tu, tv) && t > R(0) && t < dist) { shadowed = true; return true; }
+            return false;
+        }
+        R t[4], tu, tv;
+        int n = leaf_hits(S, p.idx, ray, t, tu, tv);
+        for (int k = 0; k < n; k++)
+            if (t[k] > R(0) && t[k] < dist) { shadowed = true; return true; }
+        return false;
+    }
+};
+
+// The container walk of prepare_computations (renderer.py:224-242) without a sorted list.
+// An object is in `containers` just before the hit iff an odd number of its intersections
+// precede the hit, and its place in the list is that of its LAST such intersection.  So one
+// order-free pass over every leaf the LINE meets gives: parity and last-t of the hit leaf X,
+// and among the others the odd-parity leaf Y with the largest last-t.
+template <class R> struct ContainerVisitor {
+    const DScene<R>& S; const Ray<R>& ray;
+    R t_hit; int x_leaf;
+    bool x_odd; R x_last;
+    int y_leaf; R y_last;
+    __device__ __forceinline__ ContainerVisitor(const DScene<R>& s, const Ray<R>& r, R th, int xl)
+        : S(s), ray(r), t_hit(th), x_leaf(xl), x_odd(false), x_last(-inf_<R>()), y_leaf(-1), y_last(-inf_<R>()) {}
+    __device__ __forceinline__ R limit() const { return t_hit; }
+    __device__ __forceinline__ void account(int leaf, int count, R last) {
+        if (!(count & 1)) return;
+        if (leaf == x_leaf) { x_odd = true; x_last = last; }
+        else if (last > y_last || y_leaf < 0) { y_last = last; y_leaf = leaf; }
+    }
+    __device__ __forceinline__ bool prim(int32_t code) {
+        PrimCode p(code);
+        if (p.kind == RTC_CSG_ROOT) {
+            CsgHits<R> H;
+            csg_hits(S, p.idx, ray, H);
+            for (int i = 0; i < H.n; i++) {
+                if (!(H.t[i] < t_hit)) break;
+                int leaf = H.leaf[i];
+                bool seen = false;
+                for (int j = 0; j < i; j++) seen = seen || H.leaf[j] == leaf;
+                if (seen) continue;
+                int cnt = 0; R last = -inf_<R>();
+                for (int j = i; j < H.n && H.t[j] < t_hit; j++) if (H.leaf[j] == leaf) { cnt++; last = H.t[j]; }
+                account(leaf, cnt, last);
+            }
+            return false;
+        }
+        R t[4], tu, tv; int n, leaf;
+        if (p.kind == RTC_TRIANGLE) { n = tri_hit(S.tri_geom + 12 * (size_t)p.idx, ray, t[0], tu, tv) ? 1 : 0; leaf = S.tri_leaf[p.idx]; }
+        else { leaf = p.idx; n = leaf_hits(S, leaf, ray, t, tu, tv); }
+        int cnt = 0; R last = -inf_<R>();
+        for (int k = 0; k < n; k++) if (t[k] < t_hit) { cnt++; last = max_(last, t[k]); }
+        account(leaf, cnt, last);
+        return false;
+    }
+};
+
+// ------------------------------------------------------------------------------------------
+// normals (shapes.py:275-296 collapsed; local normals :537-858)
+// ------------------------------------------------------------------------------------------
+template <class R> __device__ __forceinline__ V3<R> normal_at(const DScene<R>& S, int leaf, V3<R> wp, R hu, R hv) {
+    int kind = S.leaf_kind[leaf];
+    if (kind == RTC_TRIANGLE) {
+        const R* nn = S.tri_norm + 12 * (size_t)S.leaf_tri[leaf];
+        V3<R> n1 = mk<R>(nn[0], nn[1], nn[2]), n2 = mk<R>(nn[3], nn[4], nn[5]), n3 = mk<R>(nn[6], nn[7], nn[8]);
+        return normalize(n2 * hu + n3 * hv + n1 * (R(1) - hu - hv));
+    }
+    const R* m = S.xform + 12 * (size_t)S.leaf_xform[leaf];
+    V3<R> p = xpoint(m, wp);
+    V3<R> n;
+    switch (kind) {
+    case RTC_SPHERE: n = p; break;
+    case RTC_PLANE: n = mk<R>(0, 1, 0); break;
+    case RTC_CUBE: {
+        R ax = abs_(p.x), ay = abs_(p.y), az = abs_(p.z);
+        R maxc = pymax3(ax, ay, az);
+        if (isclose(maxc, ax)) n = mk<R>(p.x, 0, 0);
+        else if (isclose(maxc, ay)) n = mk<R>(0, p.y, 0);
+        else n = mk<R>(0, 0, p.z);
+        break;
+    }
+    default: {   // cylinder / cone: caps by `dist < 1` in both (shapes.py:676-687, 767-774)
+        R dist = p.x * p.x + p.z * p.z;
+        R minimum = S.leaf_minmax[2 * leaf], maximum = S.leaf_minmax[2 * leaf + 1];
+        if (dist < R(1) && (maximum - RTC_EPS) < p.y) n = mk<R>(0, 1, 0);
+        else if (dist < R(1) && (minimum + RTC_EPS) > p.y) n = mk<R>(0, -1, 0);
+        else if (kind == RTC_CYLINDER) n = mk<R>(p.x, 0, p.z);
+        else { R y = sqrt_(dist); if (p.y > R(0)) y = -y; n = mk<R>(p.x, y, p.z); }
+        break;
+    }
+    }
+    return normalize(xtvector(m, n));
+}
+
+// ------------------------------------------------------------------------------------------
+// patterns (shapes.py:1614-2033)
+// ------------------------------------------------------------------------------------------
+template <class R> __device__ __forceinline__ V3<R> uv_pattern_at(const DScene<R>& S, int p, R u, R v) {
+    int type = S.pat_type[p];
+    if (type == RTC_UV_CHECKER) {
+        R u2 = floor_(u * S.pat_param[4 * p]), v2 = floor_(v * S.pat_param[4 * p + 1]);
+        const R* q = S.pat_ab + 6 * p + (pymod(u2 + v2, R(2)) == R(0) ? 0 : 3);
+        return mk<R>(q[0], q[1], q[2]);
+    }
+    if (type == RTC_UV_ALIGN) {
+        int k = 0;
+        if (v > R(0.8)) { if (u < R(0.2)) k = 1; else if (u > R(0.8)) k = 2; }
+        else if (v < R(0.2)) { if (u < R(0.2)) k = 3; else if (u > R(0.8)) k = 4; }
+        const R* q = S.pat_colors + 15 * p + 3 * k;
+        return mk<R>(q[0], q[1], q[2]);
+    }
+    // RTC_UV_IMAGE: shapes.py:1975-1979, canvas.py:49-55 (np.round = half-to-even = rint)
+    int tx = S.pat_tex[p];
+    int w = S.tex_w[tx], h = S.tex_h[tx];
+    R y = u * R(w - 1), x = (R(1) - v) * R(h - 1);
+    int row = (int)rint_(x), col = (int)rint_(y);
+    if (row < 0) row += h;
+    if (col < 0) col += w;
+    row = row < 0 ? 0 : (row >= h ? h - 1 : row);   // the reference raises IndexError out of range
+    col = col < 0 ? 0 : (col >= w ? w - 1 : col);
+    const uint8_t* px = S.tex_data + S.tex_off[tx] + 3 * ((size_t)row * w + col);
+    R sc = S.tex_scale[tx];
+    return mk<R>(R(px[0]) / sc, R(px[1]) / sc, R(px[2]) / sc);
+}
+
+template <class R> __device__ __forceinline__ V3<R> pattern_at(const DScene<R>& S, int p, V3<R> pt, V3<R> a, V3<R> b) {
+    const R PI = R(3.141592653589793238462643383279502884);
+    const int32_t* ch = S.pat_child + 6 * p;
+    switch (S.pat_type[p]) {
+    case RTC_PAT_TEST: return pt;
+    case RTC_PAT_CHECKERS: {
+        R s = floor_(pt.x) + floor_(pt.y) + floor_(pt.z);
+        return abs_(pymod(s, R(2))) <= R(1e-8) ? a : b;
+    }
+    case RTC_PAT_GRADIENT: return a + (b - a) * (pt.x - floor_(pt.x));
+    case RTC_PAT_RADIAL: { R mag = sqrt_(pt.x * pt.x + pt.z * pt.z); return a + (b - a) * (mag - floor_(mag)); }
+    case RTC_PAT_RING: return pymod(floor_(sqrt_(pt.x * pt.x + pt.z * pt.z)), R(2)) == R(0) ? a : b;
+    case RTC_PAT_STRIPE: return pymod(floor_(pt.x), R(2)) == R(0) ? a : b;
+    case RTC_PAT_MAP_PLANAR: return uv_pattern_at(S, ch[0], pymod(pt.x, R(1)), pymod(pt.z, R(1)));
+    case RTC_PAT_MAP_SPHERICAL: {
+        R theta = atan2_(pt.x, pt.z);
+        R radius = sqrt_(dot(pt, pt));
+        R phi = acos_(pt.y / radius);
+        R raw_u = theta / (R(2) * PI);
+        return uv_pattern_at(S, ch[0], R(1) - (raw_u + R(0.5)), R(1) - phi / PI);
+    }
+    case RTC_PAT_MAP_CYLINDRICAL: {
+        R radius = sqrt_(pt.x * pt.x + pt.z * pt.z), abs_y = abs_(pt.y);
+        R coord = radius; if (abs_y > coord) coord = abs_y;
+        int face = (coord == radius) ? 0 : 1;
+        R raw_u = atan2_(pt.z, pt.x) / (R(2) * PI);
+        return uv_pattern_at(S, ch[face], R(1) - (raw_u + R(0.5)), pymod(pt.y, R(1)));
+    }
+    default: {   // RTC_PAT_MAP_CUBE
+        R coord = pymax3(abs_(pt.x), abs_(pt.y), abs_(pt.z));
+        int face; R u, v;
+        if (coord == pt.x) face = 0; else if (coord == -pt.x) face = 1;
+        else if (coord == pt.y) face = 2; else if (coord == -pt.y) face = 3;
+        else if (coord == pt.z) face = 4; else face = 5;
+        switch (face) {
+        case 0: u = pymod(R(1) - pt.z, R(2)) / R(2); v = pymod(pt.y + R(1), R(2)) / R(2); break;
+        case 1: u = pymod(pt.z + R(1), R(2)) / R(2); v = pymod(pt.y + R(1), R(2)) / R(2); break;
+        case 2: u = pymod(pt.x + R(1), R(2)) / R(2); v = pymod(R(1) - pt.z, R(2)) / R(2); break;
+        case 3: u = pymod(pt.x + R(1), R(2)) / R(2); v = pymod(pt.z + R(1), R(2)) / R(2); break;
+        case 4: u = pymod(pt.x + R(1), R(2)) / R(2); v = pymod(pt.y + R(1), R(2)) / R(2); break;
+        default: u = pymod(R(1) - pt.x, R(2)) / R(2); v = pymod(pt.y + R(1), R(2)) / R(2); break;
+        }
+        return uv_pattern_at(S, ch[face], u, v);
+    }
+    }
+}
+
+// material colour at a world point: plain colour, or the pattern program (postfix over a colour stack)
+template <class R> __device__ __forceinline__ V3<R> surface_color(const DScene<R>& S, int material, int leaf, V3<R> wp) {
+    int prog = S.mat_program[material];
+    const R* mc = S.mat + 10 * (size_t)material;
+    if (prog < 0) return mk<R>(mc[0], mc[1], mc[2]);
+    V3<R> op = xpoint(S.xform + 12 * (size_t)S.leaf_xform[leaf], wp);   // shape.world_to_object (shapes.py:1664)
+    int off = S.prog_off[prog], len = S.prog_len[prog];
+    V3<R> stack[RTC_PAT_STACK];
+    int sp = 0;
+    for (int i = 0; i < len; i++) {
+        int opc = S.instr[2 * (off + i)], node = S.instr[2 * (off + i) + 1];
+        if (opc == RTC_OP_BLEND) {
+            V3<R> q = stack[--sp], p = stack[--sp];
+            stack[sp++] = (p + q) * R(0.5);
+        } else {
+            V3<R> a, b;
+            if (opc == RTC_OP_EVAL_AB) { b = stack[--sp]; a = stack[--sp]; }
+            else { const R* q = S.pat_ab + 6 * node; a = mk<R>(q[0], q[1], q[2]); b = mk<R>(q[3], q[4], q[5]); }
+            V3<R> pp = xpoint(S.pat_inv + 12 * (size_t)node, op);   // inverse(pattern.transform) * object_point
+            V3<R> c = pattern_at(S, node, pp, a, b);
+            if (len == 1) return c;
+            stack[sp++] = c;
+        }
+    }
+    return stack[0];
+}
+
+// ------------------------------------------------------------------------------------------
+// counter-based RNG for jittered area lights (the reference's own jitter is not reproducible)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t hash32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return x;
+}
+template <class R> __device__ __forceinline__ R jitter01(uint64_t seed, uint32_t pixel, uint32_t ray_no, uint32_t light, uint32_t cell, uint32_t stream) {
+    uint32_t h = hash32((uint32_t)seed ^ hash32(pixel + 0x9e3779b9U * (ray_no + 1)));
+    h = hash32(h ^ hash32(light * 0x85ebca6bU + cell * 4u + stream));
+    return R(h >> 8) * R(1.0 / 16777216.0);
+}
+
+// ------------------------------------------------------------------------------------------
+// the trace loop for one pixel
+// ------------------------------------------------------------------------------------------
+template <class R> struct Bounce { V3<R> o, d, w; int remaining; };
+
+template <class R> struct Counters { unsigned int c[4]; };
+
+template <class R>
+__device__ __forceinline__ bool is_shadowed(const DScene<R>& S, V3<R> light_position, V3<R> point, int* stack, Counters<R>& cnt) {
+    V3<R> v = light_position - point;
+    R distance = sqrt_(dot(v, v));
+    Ray<R> r = {point, v * (R(1) / distance)};
+    cnt.c[1]++;
+    ShadowVisitor<R> vis(S, r, distance);
+    traverse(S, r, R(0), vis, stack);
+    return vis.shadowed;
+}
+
+template <class R>
+__device__ __forceinline__ V3<R> light_point(const DScene<R>& S, int l, int u, int v, R ju, R jv) {
+    const R* g = S.light_geom + 9 * l;
+    return mk<R>(g[0], g[1], g[2]) + mk<R>(g[3], g[4], g[5]) * (R(u) + ju) + mk<R>(g[6], g[7], g[8]) * (R(v) + jv);
+}
+
+// shade_hit's light loop: intensity_at (renderer.py:919-922, 964-973) + lighting (:1066-1090)
+template <class R>
+__device__ __forceinline__ V3<R> light_surface(const DScene<R>& S, int material, int leaf, V3<R> over_point, V3<R> eyev, V3<R> normalv,
+                                               int* stack, Counters<R>& cnt, uint64_t seed, uint32_t pixel, uint32_t ray_no) {
+    const R* m = S.mat + 10 * (size_t)material;
+    R ambient = m[3], diffuse = m[4], specular = m[5], shininess = m[6];
+    V3<R> pcolor = surface_color(S, material, leaf, over_point);
+    V3<R> surface = mk<R>(0, 0, 0);
+    for (int l = 0; l < S.n_lights; l++) {
+        const R* li = S.light_intensity + 3 * l;
+        V3<R> lint = mk<R>(li[0], li[1], li[2]);
+        V3<R> effective = pcolor * lint;
+        V3<R> amb = effective * ambient;
+        bool area = S.light_type[l] == 1;
+        int usteps = area ? S.light_steps[3 * l] : 1, vsteps = area ? S.light_steps[3 * l + 1] : 1;
+        bool jitter = area && S.light_steps[3 * l + 2] != 0;
+        int samples = usteps * vsteps;
+        // intensity_at
+        int lit = 0;
+        for (int v = 0; v < vsteps; v++)
+            for (int u = 0; u < usteps; u++) {
+                R ju = R(0.5), jv = R(0.5);
+                if (jitter) { ju = jitter01<R>(seed, pixel, ray_no, l, v * usteps + u, 0); jv = jitter01<R>(seed, pixel, ray_no, l, v * usteps + u, 1); }
+                V3<R> pos = area ? light_point(S, l, u, v, ju, jv) : mk<R>(S.light_geom[9 * l], S.light_geom[9 * l + 1], S.light_geom[9 * l + 2]);
+                if (!is_shadowed(S, pos, over_point, stack, cnt)) lit++;
+            }
+        R intensity = R(lit) / R(samples);
+        if (lit == 0) { surface = surface + amb; continue; }
+        // lighting: a FRESH set of surface points (renderer.py:1077 -> 957-962)
+        V3<R> acc = mk<R>(0, 0, 0);
+        for (int v = 0; v < vsteps; v++)
+            for (int u = 0; u < usteps; u++) {
+                R ju = R(0.5), jv = R(0.5);
+                if (jitter) { ju = jitter01<R>(seed, pixel, ray_no, l, v * usteps + u, 2); jv = jitter01<R>(seed, pixel, ray_no, l, v * usteps + u, 3); }
+                V3<R> pos = area ? light_point(S, l, u, v, ju, jv) : mk<R>(S.light_geom[9 * l], S.light_geom[9 * l + 1], S.light_geom[9 * l + 2]);
+                V3<R> lightv = normalize(pos - over_point);
+                R ldn = dot(lightv, normalv);
+                if (ldn >= R(0)) {
+                    acc = acc + effective * diffuse * ldn;
+                    V3<R> reflectv = reflect(neg(lightv), normalv);
+                    R rde = dot(reflectv, eyev);
+                    if (rde > R(0)) acc = acc + lint * specular * pow_(rde, shininess);
+                }
+            }
+        surface = surface + amb + mk<R>(acc.x / R(samples), acc.y / R(samples), acc.z / R(samples)) * intensity;
+    }
+    return surface;
+}
+
+// color_at for one primary ray, recursion unrolled into a stack of pending rays
+template <class R>
+__device__ __forceinline__ V3<R> trace_pixel(const DScene<R>& S, Ray<R> primary, int max_depth, R shade_eps, int* stack,
+                                             Counters<R>& cnt, uint64_t seed, uint32_t pixel, int& hit_leaf_out) {
+    Bounce<R> pending[RTC_MAX_BOUNCE_STACK];
+    int np = 0;
+    V3<R> color = mk<R>(0, 0, 0);
+    Ray<R> ray = primary;
+    V3<R> weight = mk<R>(1, 1, 1);
+    int remaining = max_depth;
+    uint32_t ray_no = 0;
+    hit_leaf_out = -1;
+    while (true) {
+        NearestVisitor<R> nv(S, ray);
+        traverse(S, ray, R(0), nv, stack);
+        if (ray_no == 0) hit_leaf_out = nv.leaf;
+        if (nv.leaf >= 0) {
+            // prepare_computations (renderer.py:206-222)
+            int leaf = nv.leaf;
+            R t = nv.best;
+            V3<R> point = ray.o + ray.d * t;
+            V3<R> normalv = normal_at(S, leaf, point, nv.u, nv.v);
+            V3<R> eyev = neg(ray.d);
+            V3<R> reflectv = reflect(ray.d, normalv);
+            if (dot(normalv, eyev) < R(0)) normalv = neg(normalv);
+            V3<R> over_point = point + normalv * shade_eps;
+            V3<R> under_point = point - normalv * shade_eps;
+            int material = S.leaf_material[leaf];
+            const R* m = S.mat + 10 * (size_t)material;
+            R reflective = m[7], transparency = m[8];
+
+            V3<R> surface = light_surface(S, material, leaf, over_point, eyev, normalv, stack, cnt, seed, pixel, ray_no);
+            color = color + weight * surface;
+
+            if (remaining > 0 && (reflective != R(0) || transparency != R(0))) {
+                R wrefl = reflective, wrefr = transparency;
+                bool do_refr = false;
+                V3<R> refr_dir = mk<R>(0, 0, 0);
+                if (transparency != R(0)) {
+                    // n1 / n2 (renderer.py:224-242) via the order-free container pass
+                    ContainerVisitor<R> cv(S, ray, t, leaf);
+                    traverse(S, ray, -inf_<R>(), cv, stack);
+                    R ri_x = m[9];
+                    R ri_y = cv.y_leaf >= 0 ? S.mat[10 * (size_t)S.leaf_material[cv.y_leaf] + 9] : R(1);
+                    R n1, n2;
+                    if (cv.x_odd) { n1 = (cv.y_leaf >= 0 && cv.y_last > cv.x_last) ? ri_y : ri_x; n2 = ri_y; }
+                    else { n1 = ri_y; n2 = ri_x; }
+                    // refracted_color (renderer.py:339-350)
+                    R n_ratio = n1 / n2;
+                    R cos_i = dot(eyev, normalv);
+                    R sin2_t = n_ratio * n_ratio * (R(1) - cos_i * cos_i);
+                    if (!(sin2_t > R(1))) {
+                        R cos_t = sqrt_(R(1) - sin2_t);
+                        refr_dir = normalv * (n_ratio * cos_i - cos_t) - eyev * n_ratio;
+                        do_refr = true;
+                    }
+                    if (reflective > R(0) && transparency > R(0)) {
+                        // schlick (renderer.py:272-283)
+                        R cosv = cos_i, reflectance;
+                        bool tir = false;
+                        if (n1 > n2) {
+                            R n = n1 / n2;
+                            R s2 = n * n * (R(1) - cosv * cosv);
+                            if (s2 > R(1)) tir = true; else cosv = sqrt_(R(1) - s2);
+                        }
+                        if (tir) reflectance = R(1);
+                        else {
+                            R r0 = (n1 - n2) / (n1 + n2); r0 = r0 * r0;
+                            R om = R(1) - cosv;
+                            reflectance = r0 + (R(1) - r0) * (om * om * om * om * om);
+                        }
+                        wrefl *= reflectance;
+                        wrefr *= (R(1) - reflectance);
+                    }
+                }
+                if (do_refr && np < RTC_MAX_BOUNCE_STACK) {
+                    Bounce<R> b = {under_point, refr_dir, weight * wrefr, remaining - 1};
+                    pending[np++] = b;
+                    cnt.c[3]++;
+                }
+                if (reflective != R(0) && np < RTC_MAX_BOUNCE_STACK) {
+                    Bounce<R> b = {over_point, reflectv, weight * wrefl, remaining - 1};
+                    pending[np++] = b;
+                    cnt.c[2]++;
+                }
+            }
+        }
+        if (np == 0) break;
+        np--;
+        ray.o = pending[np].o; ray.d = pending[np].d; weight = pending[np].w; remaining = pending[np].remaining;
+        ray_no++;
+    }
+    return color;
+}
+
+// renderer.py:742-751
+template <class R> __device__ __forceinline__ Ray<R> ray_for_pixel(const DCamera<R>& cam, int px, int py) {
+    R xoffset = (R(px) + R(0.5)) * cam.pixel_size, yoffset = (R(py) + R(0.5)) * cam.pixel_size;
+    R world_x = cam.half_width - xoffset, world_y = cam.half_height - yoffset;
+    V3<R> pixel = xpoint(cam.inv, mk<R>(world_x, world_y, R(-1)));
+    V3<R> origin = xpoint(cam.inv, mk<R>(0, 0, 0));
+    Ray<R> r = {origin, normalize(pixel - origin)};
+    return r;
+}
+
+}  // namespace rtc

@@ -6,7 +6,7 @@ fast path past OBJ parsing.  The pack holds this package's own description of th
 JSON tree + numeric arrays), so `load_scene(save_scene(...))` compiles to the same buffers.
 Runs of triangles inside a group are stored as one `(n, 18)` array (p1 p2 p3 n1 n2 n3).
 """
-import io
+import hashlib
 import json
 
 import numpy as np
@@ -41,6 +41,7 @@ class _Saver(object):
         self.materials, self._mat = [], {}
         self.patterns, self._pat = [], {}
         self._tex = {}
+        self._mesh_of = {}
 
     def material(self, m):
         if id(m) not in self._mat:
@@ -132,8 +133,12 @@ class _Saver(object):
 
     def _flush(self, run, kids):
         if run:
-            key = "mesh_%d" % sum(1 for k in self.arrays if k.startswith("mesh_"))
-            self.arrays[key] = self._tri_rows(run)
+            rows = self._tri_rows(run)
+            digest = hashlib.sha1(rows.tobytes()).hexdigest()
+            key = self._mesh_of.get(digest)
+            if key is None:     # identical meshes (several instances of one OBJ) are stored once
+                key = self._mesh_of[digest] = "mesh_%d" % len(self._mesh_of)
+                self.arrays[key] = rows
             kids.append({"kind": "SmoothTriangleRun", "array": key, "material": self.material(run[0].material)})
             del run[:]
 
