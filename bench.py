@@ -1,0 +1,245 @@
+#!/usr/bin/env python3
+"""bench.py -- Mrays/s (primary + secondary) of the MI355X trace loop on the dragon scene.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one whole frame of the workload: bounding_boxes.yml (6 dragon instances of 23 490
+triangles + translucent bounding cubes + reflective pedestals, 4 point lights) re-targeted to
+1920x1080, reflection/refraction depth 5 (BASELINE.json configs[4], the config the metric is
+quoted on; it fits one GPU).  The compiled scene and the framebuffer are resident in HBM before
+the timed region starts.  With N > 1 the frame's 32x32 tiles are dealt round-robin to the ranks
+(tile i -> rank i mod N), each rank traces its tiles into a compact buffer, and one RCCL gather
+brings them to rank 0, which un-permutes them into the [x][y][c] canvas -- all inside the step.
+Total work is fixed as N grows ("strong").  Rays are counted by the kernels.
+
+The headline value is measured in fp64, the reference's arithmetic; the fp32 throughput mode is
+timed right after it and reported beside it (`fp32`), never as `value`.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# per-work-item flop and byte prices (restated in DESIGN.md)
+FLOPS_AABB, FLOPS_TRI, FLOPS_XFORM, FLOPS_ANALYTIC = 24, 57, 30, 40
+FLOPS_SHADE, FLOPS_LIGHT, FLOPS_REFRACT = 85, 45, 40
+PEAK_TFLOPS = {"fp64": 78.6, "fp32": 157.3}      # MI355X vector peaks (MI355X_MICROARCH.md; fp64 = half the fp32 rate)
+
+
+def algorithmic_flops(work):
+    node, tri, leaf, csg, shade, light, container, pattern = work
+    return (2 * FLOPS_AABB * node + FLOPS_TRI * tri + (FLOPS_XFORM + FLOPS_ANALYTIC) * leaf + FLOPS_SHADE * shade +
+            FLOPS_LIGHT * light + FLOPS_REFRACT * container)
+
+
+def algorithmic_bytes(work, real_bytes):
+    node, tri, leaf = work[0], work[1], work[2]
+    # a node visit reads both child boxes (12 reals) + 2 child refs; a triangle test p1,e1,e2,eps (10 reals);
+    # an analytic leaf test its 3x4 (12 reals)
+    return node * (12 * real_bytes + 8) + tri * 10 * real_bytes + leaf * 12 * real_bytes
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--scene", default="dragons")
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--depth", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=65536, help="upper bound on pixels traced by the CPU oracle")
+    args = ap.parse_args()
+
+    import torch
+    from ray_tracer_challenge_amd import _ffi
+    from ray_tracer_challenge_amd.compile import compile_scene
+    from ray_tracer_challenge_amd.scene_io import load_world
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+        raise SystemExit("WORLD_SIZE %d != --gpus %d" % (world, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the trace loop)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    cam, scene_world, _ = load_world(os.path.join(ROOT, "scenes", args.scene + ".npz"))
+    cam = cam.resized(args.width, args.height)
+    cs = compile_scene(scene_world)
+    scene = _ffi.Scene(cs, device=local_rank)
+    info = scene.info()
+
+    T = 32
+    tx, ty = _ffi.tiles_for(cam.hsize, cam.vsize, T)
+    all_tiles = np.arange(tx * ty, dtype=np.int32)
+    mine = all_tiles[rank::world]
+    per_rank = (len(all_tiles) + world - 1) // world          # gather needs equal-sized pieces
+    tiles_dev = torch.from_numpy(mine.copy()).to(dev)
+    compact = torch.zeros((per_rank, T, T, 3), dtype=torch.float64, device=dev)
+    rays_dev = torch.zeros(12, dtype=torch.int64, device=dev)
+    frame = torch.zeros((cam.hsize, cam.vsize, 3), dtype=torch.float64, device=dev) if rank == 0 else None
+    gathered = [torch.zeros_like(compact) for _ in range(world)] if (rank == 0 and world > 1) else None
+    # destination (x, y) of every compact pixel of every rank, for the un-permute on rank 0
+    if rank == 0:
+        slots = np.concatenate([np.pad(all_tiles[r::world], (0, per_rank - len(all_tiles[r::world])), constant_values=-1)
+                                for r in range(world)])
+        ly, lx = np.meshgrid(np.arange(T), np.arange(T), indexing="ij")
+        gx = (slots[:, None, None] % tx) * T + lx[None]
+        gy = (slots[:, None, None] // tx) * T + ly[None]
+        ok = (slots[:, None, None] >= 0) & (gx < cam.hsize) & (gy < cam.vsize)
+        dst = torch.from_numpy((gx * cam.vsize + gy)[ok].astype(np.int64)).to(dev)
+        src = torch.from_numpy(np.nonzero(ok.ravel())[0].astype(np.int64)).to(dev)
+
+    def step(precision, count_work=False):
+        stream = torch.cuda.current_stream().cuda_stream
+        if world == 1:
+            # whole frame straight into the canvas layout
+            scene.render_device(cam, frame.data_ptr(), rays_ptr=rays_dev.data_ptr(), precision=precision,
+                                max_depth=args.depth, tile_size=T, stream=stream, count_work=count_work)
+            return
+        scene.render_device(cam, compact.data_ptr(), rays_ptr=rays_dev.data_ptr(), tile_ids_ptr=tiles_dev.data_ptr(),
+                            n_tiles=len(mine), precision=precision, max_depth=args.depth, tile_size=T, stream=stream,
+                            count_work=count_work)
+        dist.gather(compact, gathered, dst=0)
+        if rank == 0:
+            flat = torch.cat([g.reshape(-1, 3) for g in gathered], dim=0)
+            frame.view(-1, 3).index_copy_(0, dst, flat.index_select(0, src))
+
+    def sync():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    def timed(precision, steps, warmup):
+        for _ in range(warmup):
+            step(precision)
+        sync()
+        rays_dev.zero_()
+        torch.cuda.synchronize()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step(precision)
+        sync()
+        dt = time.perf_counter() - t0
+        dt_t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        rays_t = rays_dev[:4].clone()
+        if dist is not None:
+            dist.all_reduce(dt_t, op=dist.ReduceOp.MAX)
+            dist.all_reduce(rays_t, op=dist.ReduceOp.SUM)
+        return float(dt_t.item()), [int(v) for v in rays_t.tolist()]
+
+    def kernel_only(precision, steps):
+        """Average duration of the trace kernel alone on this rank, HIP events on its stream."""
+        stream = torch.cuda.current_stream().cuda_stream
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(steps):
+            if world == 1:
+                scene.render_device(cam, frame.data_ptr(), precision=precision, max_depth=args.depth, tile_size=T, stream=stream)
+            else:
+                scene.render_device(cam, compact.data_ptr(), tile_ids_ptr=tiles_dev.data_ptr(), n_tiles=len(mine),
+                                    precision=precision, max_depth=args.depth, tile_size=T, stream=stream)
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / steps
+
+    out = {}
+    dt, rays = timed("fp64", args.steps, args.warmup)
+    total_rays = sum(rays)
+    value = total_rays / dt / 1e6
+    kms64 = kernel_only("fp64", max(3, min(args.steps, 10)))
+    # work counters from the instrumented variant (untimed), for the roofline numerator
+    rays_dev.zero_()
+    step("fp64", count_work=True)
+    sync()
+    work = [int(v) for v in rays_dev[4:12].tolist()]
+    dt32, rays32 = timed("fp32", args.steps, args.warmup)
+    kms32 = kernel_only("fp32", max(3, min(args.steps, 10)))
+
+    if rank == 0:
+        flops = algorithmic_flops(work)
+        achieved = flops / (kms64 * 1e-3) / 1e12
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            with open(tpath) as f:
+                traffic = json.load(f).get("hbm_bytes_per_launch_fp64")
+        out = {
+            "metric": "Mrays/sec (primary+secondary)", "value": round(value, 3), "unit": "Mrays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "bounding_boxes.yml (6x dragon.obj, 140940 triangles + bbox cubes + pedestals, 4 lights) "
+                                   "at %dx%d, depth %d" % (cam.hsize, cam.vsize, args.depth),
+                       "scene_pack": args.scene, "tile": T, "parallelism": "tiles%d" % world,
+                       "bvh_nodes": info["bvh_nodes"], "bvh_depth": info["bvh_depth"]},
+            "rays_per_frame": {"primary": rays[0] // args.steps, "shadow": rays[1] // args.steps,
+                               "reflection": rays[2] // args.steps, "refraction": rays[3] // args.steps},
+            "ms_per_frame": round(dt / args.steps * 1e3, 4),
+            "fp32": {"value": round(sum(rays32) / dt32 / 1e6, 3), "unit": "Mrays/s", "ms_per_frame": round(dt32 / args.steps * 1e3, 4),
+                     "kernel_ms": round(kms32, 4)},
+            "roofline": {"bound": "valu", "achieved": round(achieved, 4), "peak": PEAK_TFLOPS["fp64"], "unit": "TFLOP/s",
+                         "frac": round(achieved / PEAK_TFLOPS["fp64"], 5), "traffic": traffic,
+                         "kernel": "trace_kernel<double>", "kernel_ms": round(kms64, 4),
+                         "algorithmic_flops_per_launch": flops, "algorithmic_bytes_per_launch": algorithmic_bytes(work, 8),
+                         "work_per_launch": dict(zip(["bvh_node_visits", "triangle_tests", "analytic_leaf_tests", "csg_evals",
+                                                      "shaded_hits", "light_samples", "container_passes", "pattern_evals"], work))},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(scene_world, cam, args.depth, args.cpu_sample)
+        print(json.dumps(out), flush=True)
+    scene.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(scene_world, cam, depth, n_sample):
+    """The CPU oracle (a C port of the reference's trace loop: every leaf for every ray, as the
+    reference does) on a bounded, evenly strided sample of the same frame's pixels."""
+    from oracle.oracle import Oracle
+    threads = min(16, os.cpu_count() or 1)
+    n = cam.hsize * cam.vsize
+    idx = (np.arange(n_sample, dtype=np.int64) * n) // n_sample + (n // n_sample) // 2
+    idx = np.minimum(idx, n - 1)
+    px, py = (idx % cam.hsize).astype(np.int32), (idx // cam.hsize).astype(np.int32)
+    o = Oracle(scene_world)
+    # chunks of the strided sample until ~12 s of CPU work have been done (bounded: <= n_sample pixels)
+    order = np.random.default_rng(0).permutation(n_sample)
+    px, py = px[order], py[order]
+    rays = np.zeros(4, np.int64)
+    done, dt, chunk = 0, 0.0, 256
+    while done < n_sample and dt < 12.0:
+        t0 = time.perf_counter()
+        _, _, _, r = o.render_pixels(cam, px[done:done + chunk], py[done:done + chunk], remaining=depth, threads=threads)
+        dt += time.perf_counter() - t0
+        rays += r
+        done += min(chunk, n_sample - done)
+        chunk = min(chunk * 2, 8192)
+    n_sample = done
+    return {"value": round(float(rays.sum()) / dt / 1e6, 6), "unit": "Mrays/s", "cores": threads, "kind": "port",
+            "sample": "%d evenly strided pixels of the same %dx%d frame (%d rays) in %.1f s; brute-force like the reference "
+                      "(no bounding-box culling, shapes.py:454)" % (n_sample, cam.hsize, cam.vsize, int(rays.sum()), dt)}
+
+
+if __name__ == "__main__":
+    main()

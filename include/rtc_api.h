@@ -132,17 +132,24 @@ typedef struct {
     double inv_transform[12];
 } rtc_camera;
 
+/* Run the instrumented kernel variant that also counts work items (slower; for roofline
+ * accounting, never for timing). */
+#define RTC_FLAG_COUNT_WORK 1
+
 typedef struct {
     int32_t precision;   /* 64 = fp64 (reference arithmetic), 32 = fp32 throughput mode */
     int32_t max_depth;   /* the reference's `remaining`, default 5 (renderer.py:562) */
     int32_t tile_size;   /* pixels per tile edge for rtc_render_tiles*; multiple of 8; 0 -> 32 */
-    int32_t reserved;
+    int32_t flags;       /* RTC_FLAG_* */
     double shade_eps;    /* over/under-point offset; <= 0 -> 1e-6 in fp64 (renderer.py:15, :221-222), 2e-4 in fp32 */
     uint64_t seed;       /* jittered area lights only */
 } rtc_render_opts;
 
 typedef struct {
     int64_t rays[4];     /* traced: primary, shadow, reflection, refraction */
+    int64_t work[8];     /* RTC_FLAG_COUNT_WORK only: BVH node visits (2 box tests each), triangle tests,
+                            analytic leaf tests, CSG evaluations, shaded hits, light samples shaded,
+                            container passes, pattern evaluations */
     double kernel_ms;    /* trace kernel time measured with HIP events on its stream (host-buffer calls only) */
 } rtc_stats;
 
@@ -181,7 +188,8 @@ int rtc_render_tiles(rtc_scene *scene, const rtc_camera *cam, const rtc_render_o
 
 /* Device-pointer form for callers that keep the frame in HBM (bench.py, the multi-GPU gather).
  * tile_ids_dev == NULL renders the whole frame into the [x][y][c] layout; otherwise the
- * compact tile layout above.  rays_dev ([4] int64, may be NULL) is ADDED to.  Asynchronous on
+ * compact tile layout above.  rays_dev (may be NULL) is ADDED to: [4] int64 ray counts, or [12]
+ * with RTC_FLAG_COUNT_WORK ([4..11] = the work counters of rtc_stats).  Asynchronous on
  * `stream` (a hipStream_t, NULL = default stream). */
 int rtc_render_device(rtc_scene *scene, const rtc_camera *cam, const rtc_render_opts *opts,
                       int32_t n_tiles, const int32_t *tile_ids_dev,

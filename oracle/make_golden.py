@@ -1,0 +1,153 @@
+"""TEST INFRASTRUCTURE, BUILD CONTAINER ONLY.  Renders pixel subsets of the BASELINE.json scenes
+with the REFERENCE ITSELF (imported read-only from /root/reference) and commits them as small
+fixtures under tests/golden/: per pixel the reference's fp64 colour (`color_at`), the primary
+hit's leaf id and `t` (`hit(intersect_world(...))`).  These pin the CPU oracle (and through it
+the HIP path) to the reference, not to anybody's reading of it.
+
+Leaf ids are in THIS package's canonical numbering (depth-first over the scene pack's tree):
+reference leaves are matched to ours by geometry (kind + collapsed world->object matrix +
+triangle vertices), because the reference keeps group children in hash-ordered sets.
+
+    python -m oracle.make_golden [scene ...]
+"""
+import json
+import multiprocessing as mp
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+from oracle import ref_harness as rh  # noqa: E402
+from ray_tracer_challenge_amd.compile import compile_scene  # noqa: E402
+from ray_tracer_challenge_amd.scene_io import load_world  # noqa: E402
+
+REF = rh.REF
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+_G = {}
+
+
+def _ref_pixel(xy):
+    R, S = _G["mods"]["renderer"], _G["mods"]["shapes"]
+    x, y = xy
+    r = R.ray_for_pixel(_G["cam"], x, y)
+    xs = R.intersect_world(_G["world"], r)
+    h = S.hit(xs)
+    c = R.color_at(_G["world"], r)
+    return (np.asarray(c, dtype=np.float64), None if h is None else id(h.object), np.inf if h is None else float(h.t))
+
+
+def leaf_keys(cs):
+    A = cs.arrays
+    keys = []
+    for i in range(cs.counts["n_leaves"]):
+        k = [int(A["leaf_kind"][i])] + list(np.round(A["xform"][A["leaf_xform"][i]], 9)) + \
+            list(np.round(A["leaf_minmax"][i], 9)) + [int(A["leaf_closed"][i])]
+        if A["leaf_tri"][i] >= 0:
+            k += list(np.round(A["tri_geom"][A["leaf_tri"][i]][:9], 9))
+        keys.append(tuple(float(v) + 0.0 for v in k))   # + 0.0: -0.0 -> 0.0
+    return keys
+
+
+def make(name, yaml_rel, cwd, size, pixels, edit=None, divide=None, procs=8):
+    """pixels: 'all' or a stride or an explicit (px, py) pair of arrays (at `size`)."""
+    mods = rh.import_reference()
+    cam_o, world_o, objs_o = load_world(os.path.join(ROOT, "scenes", name + ".npz"))
+    ypath = os.path.join(REF, yaml_rel)
+    with rh.chdir(cwd):
+        if edit is not None:
+            with open(ypath) as f, tempfile.NamedTemporaryFile("w", suffix=".yml", delete=False) as g:
+                g.write(edit(f.read()))
+                ypath = g.name
+        objs = mods["yaml_parser"].yaml_file_to_world_objects(ypath)
+    cam = objs["camera"]
+    if size is not None:
+        cam = mods["renderer"].Camera(size[0], size[1], cam.field_of_view, cam.transform)
+        cam_o = cam_o.resized(*size)
+    if divide is not None:
+        objs["world"][0].divide(divide)
+    world = mods["renderer"].World(objs["lights"], objs["world"])
+
+    ours, theirs = compile_scene(world_o), compile_scene(world)
+    k_ours = {k: i for i, k in reversed(list(enumerate(leaf_keys(ours))))}
+    ref_to_ours = {}
+    for i, (k, obj) in enumerate(zip(leaf_keys(theirs), theirs.leaf_objects)):
+        if k not in k_ours:
+            raise RuntimeError("%s: reference leaf %d has no geometric match in the scene pack" % (name, i))
+        ref_to_ours[id(obj)] = k_ours[k]
+    assert ours.counts["n_leaves"] == theirs.counts["n_leaves"]
+
+    if isinstance(pixels, tuple):
+        px, py = np.asarray(pixels[0]), np.asarray(pixels[1])
+    else:
+        stride = 1 if pixels == "all" else int(pixels)
+        xs, ys = np.meshgrid(np.arange(stride // 2, cam.hsize, stride), np.arange(stride // 2, cam.vsize, stride), indexing="ij")
+        px, py = xs.ravel(), ys.ravel()
+    _G.update(mods=mods, cam=cam, world=world)
+    t0 = time.time()
+    with mp.get_context("fork").Pool(procs) as pool:
+        res = pool.map(_ref_pixel, list(zip(px.tolist(), py.tolist())), chunksize=max(1, len(px) // (procs * 16)))
+    dt = time.time() - t0
+    rgb = np.array([r[0] for r in res])
+    leaf = np.array([-1 if r[1] is None else ref_to_ours[r[1]] for r in res], np.int32)
+    t = np.array([r[2] for r in res])
+    meta = {"scene_pack": name, "source": yaml_rel, "hsize": int(cam.hsize), "vsize": int(cam.vsize), "remaining": 5,
+            "divide": divide, "pixels": int(len(px)), "reference_seconds": round(dt, 1), "procs": procs,
+            "pack_meta": objs_o["meta"],
+            "made_by": "oracle/make_golden.py: reference color_at / hit(intersect_world) per pixel, numpy %s" % np.__version__}
+    os.makedirs(GOLD, exist_ok=True)
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), px=px.astype(np.int32), py=py.astype(np.int32), rgb=rgb,
+                        hit_leaf=leaf, hit_t=t, meta=np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8))
+    print("%-30s %5d px  %7.1f s reference  max rgb %.3f  hits %d" % (name, len(px), dt, rgb.max(), (leaf >= 0).sum()), flush=True)
+
+
+def main(which):
+    from make_scene_packs import synthetic_faces
+    tm = "texture_mapping"
+    objs_cwd = os.path.join(REF, "objects")
+    jobs = {
+        "cover": lambda: make("cover", "cover/cover.yml", REF, None, "all"),
+        "csg_test": lambda: make("csg_test", "csg_test.yml", REF, (128, 128), "all"),
+        "group": lambda: make("group", "group_test/group.yml", REF, None, 2),
+        "checkered_sphere": lambda: make("checkered_sphere", tm + "/checkered_sphere/checkered_sphere.yml", REF, (96, 96), "all"),
+        "checkered_plane": lambda: make("checkered_plane", tm + "/checkered_plane/checkered_plane.yml", REF, (96, 96), "all"),
+        "checkered_cylinder": lambda: make("checkered_cylinder", tm + "/checkered_cylinder/checkered_cylinder.yml", REF, (96, 96), "all"),
+        "align_check_plane": lambda: make("align_check_plane", tm + "/align_check_plane/align_check_plane.yml", REF, (96, 96), "all"),
+        "checkered_cube": lambda: make("checkered_cube", tm + "/checkered_cube/checkered_cube.yml", REF, (160, 80), "all"),
+        "earth": lambda: make("earth", tm + "/earth/earth.yml", REF, (160, 80), "all",
+                              edit=lambda t: t.replace("texture_mapping/earth/earthmap1k.jpg", "texture_mapping/orrery/earthmap-small.jpg")),
+        "shadow_glamour_shot_nojitter": lambda: make("shadow_glamour_shot_nojitter", "shadow_glamour_shot/shadow_glamour_shot.yml", REF,
+                                                     (150, 60), "all", edit=lambda t: t.replace("jitter: true", "jitter: false")),
+        "teapot": lambda: make("teapot", "obj_file_test/obj_file_test.yml", objs_cwd, None, 8, divide=1),
+    }
+
+    def skybox():
+        with tempfile.TemporaryDirectory() as tmp:
+            faces = synthetic_faces(tmp)
+
+            def ed(t):
+                for k, p in faces.items():
+                    t = t.replace("texture_mapping/skybox/%s.jpg" % k, p)
+                return t
+            make("skybox", tm + "/skybox/skybox.yml", REF, (160, 80), "all", edit=ed)
+    jobs["skybox"] = skybox
+
+    def dragons():
+        # 24 hand-spread pixels of the 480x192 frame: dragons, bbox cubes, pedestals, floor-less background
+        px = np.array([240, 240, 236, 250, 300, 310, 180, 170, 120, 110, 360, 370, 240, 244, 305, 175, 115, 365, 60, 420, 238, 242, 200, 280])
+        py = np.array([60, 75, 90, 100, 95, 110, 100, 112, 125, 135, 125, 135, 140, 150, 125, 128, 148, 148, 96, 96, 118, 30, 86, 86])
+        make("dragons", "bounding_box_images/bounding_boxes.yml", objs_cwd, (480, 192), (px, py))
+    jobs["dragons"] = dragons
+
+    for name in (which or list(jobs)):
+        jobs[name]()
+
+
+if __name__ == "__main__":
+    main(sys.argv[1:])

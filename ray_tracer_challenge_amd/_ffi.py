@@ -44,11 +44,11 @@ class CameraDesc(C.Structure):
 
 class RenderOpts(C.Structure):
     _fields_ = [("precision", C.c_int32), ("max_depth", C.c_int32), ("tile_size", C.c_int32),
-                ("reserved", C.c_int32), ("shade_eps", C.c_double), ("seed", C.c_uint64)]
+                ("flags", C.c_int32), ("shade_eps", C.c_double), ("seed", C.c_uint64)]
 
 
 class Stats(C.Structure):
-    _fields_ = [("rays", C.c_int64 * 4), ("kernel_ms", C.c_double)]
+    _fields_ = [("rays", C.c_int64 * 4), ("work", C.c_int64 * 8), ("kernel_ms", C.c_double)]
 
 
 class SceneInfo(C.Structure):
@@ -105,11 +105,11 @@ def make_camera(cam):
     return c
 
 
-def make_opts(precision="fp64", max_depth=5, tile_size=32, shade_eps=0.0, seed=0):
+def make_opts(precision="fp64", max_depth=5, tile_size=32, shade_eps=0.0, seed=0, count_work=False):
     bits = {"fp64": 64, "fp32": 32, 64: 64, 32: 32}.get(precision)
     if bits is None:
         raise ValueError("precision must be 'fp64' or 'fp32'")
-    return RenderOpts(bits, int(max_depth), int(tile_size), 0, float(shade_eps), int(seed))
+    return RenderOpts(bits, int(max_depth), int(tile_size), 1 if count_work else 0, float(shade_eps), int(seed))
 
 
 def make_desc(cs):
@@ -155,9 +155,10 @@ class Scene(object):
         _check(lib().rtc_scene_get_info(self.handle, C.byref(out)))
         return {k: getattr(out, k) for k, _ in SceneInfo._fields_}
 
-    def render(self, cam, precision="fp64", max_depth=5, want_ids=False, stats=None, shade_eps=0.0, seed=0):
+    def render(self, cam, precision="fp64", max_depth=5, want_ids=False, stats=None, shade_eps=0.0, seed=0,
+               count_work=False):
         """-> (rgb (hsize, vsize, 3) f64, ids (hsize, vsize) i32 or None)."""
-        c, o, st = make_camera(cam), make_opts(precision, max_depth, 32, shade_eps, seed), Stats()
+        c, o, st = make_camera(cam), make_opts(precision, max_depth, 32, shade_eps, seed, count_work), Stats()
         rgb = np.zeros((c.hsize, c.vsize, 3), np.float64)
         ids = np.full((c.hsize, c.vsize), -1, np.int32) if want_ids else None
         _check(lib().rtc_render(self.handle, C.byref(c), C.byref(o), rgb.ctypes.data_as(_P),
@@ -179,9 +180,9 @@ class Scene(object):
         return rgb, ids
 
     def render_device(self, cam, rgb_ptr, ids_ptr=None, rays_ptr=None, tile_ids_ptr=None, n_tiles=0, precision="fp64",
-                      max_depth=5, tile_size=32, shade_eps=0.0, seed=0, stream=None):
+                      max_depth=5, tile_size=32, shade_eps=0.0, seed=0, stream=None, count_work=False):
         """Asynchronous launch on device pointers (ints, e.g. torch `tensor.data_ptr()`)."""
-        c, o = make_camera(cam), make_opts(precision, max_depth, tile_size, shade_eps, seed)
+        c, o = make_camera(cam), make_opts(precision, max_depth, tile_size, shade_eps, seed, count_work)
         _check(lib().rtc_render_device(self.handle, C.byref(c), C.byref(o), int(n_tiles), _P(tile_ids_ptr or None),
                                        _P(rgb_ptr), _P(ids_ptr or None), _P(rays_ptr or None), _P(stream or None)))
 
@@ -189,6 +190,7 @@ class Scene(object):
 def _fill_stats(stats, st):
     if stats is not None:
         stats["rays"] = [int(v) for v in st.rays]
+        stats["work"] = [int(v) for v in st.work]
         stats["kernel_ms"] = float(st.kernel_ms)
 
 

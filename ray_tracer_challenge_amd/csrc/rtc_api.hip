@@ -36,14 +36,16 @@ int fail(int code, const char* fmt, ...) {
 // ---------------------------------------------------------------------------------------------
 // kernels
 // ---------------------------------------------------------------------------------------------
-template <class R>
+template <class R, bool PROF>
 __global__ __launch_bounds__(RTC_BLOCK) void trace_kernel(rtc::DScene<R> S, rtc::DCamera<R> cam, rtc::DFrame F, R shade_eps) {
     __shared__ int s_stack[RTC_BVH_STACK * RTC_BLOCK];
     int* stack = s_stack + threadIdx.x;
     const int T = F.tile_size, per_tile = T * T, sub = T / 8;
     long long w = (long long)blockIdx.x * RTC_BLOCK + threadIdx.x;
     int slot = (int)(w / per_tile), within = (int)(w % per_tile);
-    rtc::Counters<R> cnt = {{0, 0, 0, 0}};
+    rtc::Counters<PROF> cnt;
+    for (int k = 0; k < 4; k++) cnt.c[k] = 0;
+    for (int k = 0; k < (PROF ? rtc::W_COUNT : 1); k++) cnt.w[k] = 0;
     if (slot < F.n_tiles) {
         int tile = F.tile_ids ? F.tile_ids[slot] : slot;
         int tx0 = (tile % F.tiles_x) * T, ty0 = (tile / F.tiles_x) * T;
@@ -79,6 +81,13 @@ __global__ __launch_bounds__(RTC_BLOCK) void trace_kernel(rtc::DScene<R> S, rtc:
             unsigned long long s = 0;
             for (int q = 0; q < RTC_BLOCK / 64; q++) s += red[threadIdx.x * (RTC_BLOCK / 64) + q];
             if (s) atomicAdd(F.rays + threadIdx.x, s);
+        }
+    }
+    if (PROF && F.work) {
+        for (int k = 0; k < rtc::W_COUNT; k++) {
+            unsigned int v = cnt.w[k];
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+            if ((threadIdx.x & 63) == 0 && v) atomicAdd(F.work + k, (unsigned long long)v);
         }
     }
 }
@@ -365,7 +374,7 @@ int check_render_args(const rtc_scene* scene, const rtc_camera* cam, const rtc_r
 }
 
 int launch(rtc_scene* scene, const rtc_camera* cam, const rtc_render_opts* opts, int32_t n_tiles, const int32_t* tile_ids_dev,
-           double* rgb_dev, int32_t* hit_id_dev, int64_t* rays_dev, hipStream_t stream) {
+           double* rgb_dev, int32_t* hit_id_dev, int64_t* rays_dev, int64_t* work_dev, hipStream_t stream) {
     int T, precision, depth;
     double eps;
     if (int rc = check_render_args(scene, cam, opts, &T, &precision, &depth, &eps)) return rc;
@@ -382,12 +391,15 @@ int launch(rtc_scene* scene, const rtc_camera* cam, const rtc_render_opts* opts,
     long long work = (long long)n_tiles * T * T;
     long long blocks = (work + RTC_BLOCK - 1) / RTC_BLOCK;
     if (blocks > 0x7FFFFFFFLL) return fail(RTC_ERR_LIMIT, "too many blocks");
-    if (precision == 64)
-        hipLaunchKernelGGL(trace_kernel<double>, dim3((unsigned)blocks), dim3(RTC_BLOCK), 0, stream, scene->d64,
-                           make_camera<double>(*cam), F, eps);
-    else
-        hipLaunchKernelGGL(trace_kernel<float>, dim3((unsigned)blocks), dim3(RTC_BLOCK), 0, stream, scene->d32,
-                           make_camera<float>(*cam), F, (float)eps);
+    F.work = reinterpret_cast<unsigned long long*>(work_dev);
+    dim3 grid((unsigned)blocks), block(RTC_BLOCK);
+    if (precision == 64) {
+        if (work_dev) hipLaunchKernelGGL((trace_kernel<double, true>), grid, block, 0, stream, scene->d64, make_camera<double>(*cam), F, eps);
+        else hipLaunchKernelGGL((trace_kernel<double, false>), grid, block, 0, stream, scene->d64, make_camera<double>(*cam), F, eps);
+    } else {
+        if (work_dev) hipLaunchKernelGGL((trace_kernel<float, true>), grid, block, 0, stream, scene->d32, make_camera<float>(*cam), F, (float)eps);
+        else hipLaunchKernelGGL((trace_kernel<float, false>), grid, block, 0, stream, scene->d32, make_camera<float>(*cam), F, (float)eps);
+    }
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -423,8 +435,9 @@ int render_host(rtc_scene* scene, const rtc_camera* cam, const rtc_render_opts* 
     TRY_C(hipMalloc(&d_rgb, n_px * 3 * sizeof(double)));
     if (tiled) TRY_C(hipMemset(d_rgb, 0, n_px * 3 * sizeof(double)));
     if (hit_id_out) { TRY_C(hipMalloc(&d_id, n_px * sizeof(int32_t))); TRY_C(hipMemset(d_id, 0xFF, n_px * sizeof(int32_t))); }
-    TRY_C(hipMalloc(&d_rays, 4 * sizeof(int64_t)));
-    TRY_C(hipMemset(d_rays, 0, 4 * sizeof(int64_t)));
+    const bool want_work = stats_out && opts && (opts->flags & RTC_FLAG_COUNT_WORK);
+    TRY_C(hipMalloc(&d_rays, 12 * sizeof(int64_t)));
+    TRY_C(hipMemset(d_rays, 0, 12 * sizeof(int64_t)));
     if (tiled) {
         TRY_C(hipMalloc(&d_tiles, (size_t)n_tiles * sizeof(int32_t)));
         TRY_C(hipMemcpy(d_tiles, tile_ids, (size_t)n_tiles * sizeof(int32_t), hipMemcpyHostToDevice));
@@ -432,7 +445,7 @@ int render_host(rtc_scene* scene, const rtc_camera* cam, const rtc_render_opts* 
     TRY_C(hipEventCreate(&e0));
     TRY_C(hipEventCreate(&e1));
     TRY_C(hipEventRecord(e0, nullptr));
-    rc = launch(scene, cam, opts, n_tiles, d_tiles, d_rgb, d_id, d_rays, nullptr);
+    rc = launch(scene, cam, opts, n_tiles, d_tiles, d_rgb, d_id, d_rays, want_work ? d_rays + 4 : nullptr, nullptr);
     if (rc) { cleanup(); return rc; }
     TRY_C(hipEventRecord(e1, nullptr));
     TRY_C(hipEventSynchronize(e1));
@@ -442,6 +455,7 @@ int render_host(rtc_scene* scene, const rtc_camera* cam, const rtc_render_opts* 
     if (hit_id_out) TRY_C(hipMemcpy(hit_id_out, d_id, n_px * sizeof(int32_t), hipMemcpyDeviceToHost));
     if (stats_out) {
         TRY_C(hipMemcpy(stats_out->rays, d_rays, 4 * sizeof(int64_t), hipMemcpyDeviceToHost));
+        if (want_work) TRY_C(hipMemcpy(stats_out->work, d_rays + 4, 8 * sizeof(int64_t), hipMemcpyDeviceToHost));
         stats_out->kernel_ms = ms;
     }
 #undef TRY_C
@@ -508,7 +522,8 @@ int rtc_render_tiles(rtc_scene* scene, const rtc_camera* cam, const rtc_render_o
 
 int rtc_render_device(rtc_scene* scene, const rtc_camera* cam, const rtc_render_opts* opts, int32_t n_tiles, const int32_t* tile_ids_dev,
                       double* rgb_dev, int32_t* hit_id_dev, int64_t* rays_dev, void* stream) {
-    return launch(scene, cam, opts, n_tiles, tile_ids_dev, rgb_dev, hit_id_dev, rays_dev, static_cast<hipStream_t>(stream));
+    int64_t* work = (rays_dev && opts && (opts->flags & RTC_FLAG_COUNT_WORK)) ? rays_dev + 4 : nullptr;
+    return launch(scene, cam, opts, n_tiles, tile_ids_dev, rgb_dev, hit_id_dev, rays_dev, work, static_cast<hipStream_t>(stream));
 }
 
 int rtc_quantize_device(const double* rgb_dev, int32_t hsize, int32_t vsize, double max_component, uint8_t* out_dev, void* stream) {

@@ -125,10 +125,21 @@ struct DFrame {
     int32_t n_tiles;             // tiles to render
     int32_t tile_size, tiles_x;
     const int32_t* tile_ids;     // NULL: tile k = k, output in [x][y][c]; else compact tile layout
-    double* rgb; int32_t* hit_id; unsigned long long* rays;
+    double* rgb; int32_t* hit_id; unsigned long long* rays; unsigned long long* work;
     int32_t max_depth;
     uint64_t seed;
 };
+
+// c: rays traced (primary, shadow, reflection, refraction).  w (PROF builds only): BVH node
+// visits (2 box tests each), triangle tests, analytic leaf tests, CSG root evaluations, shaded
+// hits, light samples shaded, container passes, pattern-node evaluations.
+enum { W_NODE = 0, W_TRI = 1, W_LEAF = 2, W_CSG = 3, W_SHADE = 4, W_LIGHT = 5, W_CONTAINER = 6, W_PATTERN = 7, W_COUNT = 8 };
+template <bool PROF> struct Counters {
+    unsigned int c[4];
+    unsigned int w[PROF ? W_COUNT : 1];
+    __device__ __forceinline__ void work(int k) { if (PROF) w[k]++; }
+};
+template <class R> struct Bounce { V3<R> o, d, w; int remaining; };
 
 #define RTC_EPS R(0.000001) /* renderer.py:15, shapes.py:8 */
 
@@ -309,6 +320,7 @@ template <class R, class V> __device__ __forceinline__ void traverse(const DScen
     int node = 0;
     while (true) {
         if (node >= 0) {
+            vis.cnt.work(W_NODE);
             const R* b = S.node_box + 12 * (size_t)node;
             int c0 = S.node_child[2 * node], c1 = S.node_child[2 * node + 1];
             R near[2], far[2];
@@ -346,20 +358,22 @@ template <class R, class V> __device__ __forceinline__ void traverse(const DScen
 }
 
 // hit(intersect_world(ray)) (renderer.py:75-79, shapes.py:1422-1425): smallest t > 0
-template <class R> struct NearestVisitor {
-    const DScene<R>& S; const Ray<R>& ray;
+template <class R, class CNT> struct NearestVisitor {
+    const DScene<R>& S; const Ray<R>& ray; CNT& cnt;
     R best; int leaf; R u, v;
-    __device__ __forceinline__ NearestVisitor(const DScene<R>& s, const Ray<R>& r) : S(s), ray(r), best(inf_<R>()), leaf(-1), u(0), v(0) {}
+    __device__ __forceinline__ NearestVisitor(const DScene<R>& s, const Ray<R>& r, CNT& c) : S(s), ray(r), cnt(c), best(inf_<R>()), leaf(-1), u(0), v(0) {}
     __device__ __forceinline__ R limit() const { return best; }
     __device__ __forceinline__ bool prim(int32_t code) {
         PrimCode p(code);
         if (p.kind == RTC_TRIANGLE) {
             R t, tu, tv;
+            cnt.work(W_TRI);
             if (tri_hit(S.tri_geom + 12 * (size_t)p.idx, ray, t, tu, tv) && t > R(0) && t < best) {
                 best = t; leaf = S.tri_leaf[p.idx]; u = tu; v = tv;
             }
         } else if (p.kind == RTC_CSG_ROOT) {
             CsgHits<R> H;
+            cnt.work(W_CSG);
             csg_hits(S, p.idx, ray, H);
             for (int i = 0; i < H.n; i++)
                 if (H.t[i] > R(0)) {
@@ -371,6 +385,7 @@ template <class R> struct NearestVisitor {
                 }
         } else {
             R t[4], tu, tv;
+            cnt.work(W_LEAF);
             int n = leaf_hits(S, p.idx, ray, t, tu, tv);
             for (int k = 0; k < n; k++)
                 if (t[k] > R(0) && t[k] < best) { best = t[k]; leaf = p.idx; }
@@ -380,14 +395,15 @@ template <class R> struct NearestVisitor {
 };
 
 // is_shadowed (renderer.py:552-560): any hit of a shadow-casting leaf with 0 < t < distance
-template <class R> struct ShadowVisitor {
-    const DScene<R>& S; const Ray<R>& ray; R dist; bool shadowed;
-    __device__ __forceinline__ ShadowVisitor(const DScene<R>& s, const Ray<R>& r, R d) : S(s), ray(r), dist(d), shadowed(false) {}
+template <class R, class CNT> struct ShadowVisitor {
+    const DScene<R>& S; const Ray<R>& ray; CNT& cnt; R dist; bool shadowed;
+    __device__ __forceinline__ ShadowVisitor(const DScene<R>& s, const Ray<R>& r, R d, CNT& c) : S(s), ray(r), cnt(c), dist(d), shadowed(false) {}
     __device__ __forceinline__ R limit() const { return dist; }
     __device__ __forceinline__ bool prim(int32_t code) {
         PrimCode p(code);
         if (p.kind == RTC_CSG_ROOT) {
             CsgHits<R> H;
+            cnt.work(W_CSG);
             csg_hits(S, p.idx, ray, H);
             for (int i = 0; i < H.n; i++)
                 if (H.t[i] > R(0) && H.t[i] < dist && S.mat_shadow[S.leaf_material[H.leaf[i]]]) { shadowed = true; return true; }
@@ -396,10 +412,12 @@ template <class R> struct ShadowVisitor {
         if (p.noshadow) return false;
         if (p.kind == RTC_TRIANGLE) {
             R t, tu, tv;
+            cnt.work(W_TRI);
             if (tri_hit(S.tri_geom + 12 * (size_t)p.idx, ray, t, tu, tv) && t > R(0) && t < dist) { shadowed = true; return true; }
             return false;
         }
         R t[4], tu, tv;
+        cnt.work(W_LEAF);
         int n = leaf_hits(S, p.idx, ray, t, tu, tv);
         for (int k = 0; k < n; k++)
             if (t[k] > R(0) && t[k] < dist) { shadowed = true; return true; }
@@ -412,13 +430,13 @@ template <class R> struct ShadowVisitor {
 // precede the hit, and its place in the list is that of its LAST such intersection.  So one
 // order-free pass over every leaf the LINE meets gives: parity and last-t of the hit leaf X,
 // and among the others the odd-parity leaf Y with the largest last-t.
-template <class R> struct ContainerVisitor {
-    const DScene<R>& S; const Ray<R>& ray;
+template <class R, class CNT> struct ContainerVisitor {
+    const DScene<R>& S; const Ray<R>& ray; CNT& cnt;
     R t_hit; int x_leaf;
     bool x_odd; R x_last;
     int y_leaf; R y_last;
-    __device__ __forceinline__ ContainerVisitor(const DScene<R>& s, const Ray<R>& r, R th, int xl)
-        : S(s), ray(r), t_hit(th), x_leaf(xl), x_odd(false), x_last(-inf_<R>()), y_leaf(-1), y_last(-inf_<R>()) {}
+    __device__ __forceinline__ ContainerVisitor(const DScene<R>& s, const Ray<R>& r, R th, int xl, CNT& c)
+        : S(s), ray(r), cnt(c), t_hit(th), x_leaf(xl), x_odd(false), x_last(-inf_<R>()), y_leaf(-1), y_last(-inf_<R>()) {}
     __device__ __forceinline__ R limit() const { return t_hit; }
     __device__ __forceinline__ void account(int leaf, int count, R last) {
         if (!(count & 1)) return;
@@ -429,6 +447,7 @@ template <class R> struct ContainerVisitor {
         PrimCode p(code);
         if (p.kind == RTC_CSG_ROOT) {
             CsgHits<R> H;
+            cnt.work(W_CSG);
             csg_hits(S, p.idx, ray, H);
             for (int i = 0; i < H.n; i++) {
                 if (!(H.t[i] < t_hit)) break;
@@ -443,8 +462,8 @@ template <class R> struct ContainerVisitor {
             return false;
         }
         R t[4], tu, tv; int n, leaf;
-        if (p.kind == RTC_TRIANGLE) { n = tri_hit(S.tri_geom + 12 * (size_t)p.idx, ray, t[0], tu, tv) ? 1 : 0; leaf = S.tri_leaf[p.idx]; }
-        else { leaf = p.idx; n = leaf_hits(S, leaf, ray, t, tu, tv); }
+        if (p.kind == RTC_TRIANGLE) { cnt.work(W_TRI); n = tri_hit(S.tri_geom + 12 * (size_t)p.idx, ray, t[0], tu, tv) ? 1 : 0; leaf = S.tri_leaf[p.idx]; }
+        else { cnt.work(W_LEAF); leaf = p.idx; n = leaf_hits(S, leaf, ray, t, tu, tv); }
         int cnt = 0; R last = -inf_<R>();
         for (int k = 0; k < n; k++) if (t[k] < t_hit) { cnt++; last = max_(last, t[k]); }
         account(leaf, cnt, last);
@@ -610,17 +629,16 @@ template <class R> __device__ __forceinline__ R jitter01(uint64_t seed, uint32_t
 // ------------------------------------------------------------------------------------------
 // the trace loop for one pixel
 // ------------------------------------------------------------------------------------------
-template <class R> struct Bounce { V3<R> o, d, w; int remaining; };
 
-template <class R> struct Counters { unsigned int c[4]; };
 
-template <class R>
-__device__ __forceinline__ bool is_shadowed(const DScene<R>& S, V3<R> light_position, V3<R> point, int* stack, Counters<R>& cnt) {
+
+template <class R, class CNT>
+__device__ __forceinline__ bool is_shadowed(const DScene<R>& S, V3<R> light_position, V3<R> point, int* stack, CNT& cnt) {
     V3<R> v = light_position - point;
     R distance = sqrt_(dot(v, v));
     Ray<R> r = {point, v * (R(1) / distance)};
     cnt.c[1]++;
-    ShadowVisitor<R> vis(S, r, distance);
+    ShadowVisitor<R, CNT> vis(S, r, distance, cnt);
     traverse(S, r, R(0), vis, stack);
     return vis.shadowed;
 }
@@ -632,11 +650,12 @@ __device__ __forceinline__ V3<R> light_point(const DScene<R>& S, int l, int u, i
 }
 
 // shade_hit's light loop: intensity_at (renderer.py:919-922, 964-973) + lighting (:1066-1090)
-template <class R>
+template <class R, class CNT>
 __device__ __forceinline__ V3<R> light_surface(const DScene<R>& S, int material, int leaf, V3<R> over_point, V3<R> eyev, V3<R> normalv,
-                                               int* stack, Counters<R>& cnt, uint64_t seed, uint32_t pixel, uint32_t ray_no) {
+                                               int* stack, CNT& cnt, uint64_t seed, uint32_t pixel, uint32_t ray_no) {
     const R* m = S.mat + 10 * (size_t)material;
     R ambient = m[3], diffuse = m[4], specular = m[5], shininess = m[6];
+    if (S.mat_program[material] >= 0) cnt.work(W_PATTERN);
     V3<R> pcolor = surface_color(S, material, leaf, over_point);
     V3<R> surface = mk<R>(0, 0, 0);
     for (int l = 0; l < S.n_lights; l++) {
@@ -666,6 +685,7 @@ __device__ __forceinline__ V3<R> light_surface(const DScene<R>& S, int material,
                 R ju = R(0.5), jv = R(0.5);
                 if (jitter) { ju = jitter01<R>(seed, pixel, ray_no, l, v * usteps + u, 2); jv = jitter01<R>(seed, pixel, ray_no, l, v * usteps + u, 3); }
                 V3<R> pos = area ? light_point(S, l, u, v, ju, jv) : mk<R>(S.light_geom[9 * l], S.light_geom[9 * l + 1], S.light_geom[9 * l + 2]);
+                cnt.work(W_LIGHT);
                 V3<R> lightv = normalize(pos - over_point);
                 R ldn = dot(lightv, normalv);
                 if (ldn >= R(0)) {
@@ -681,9 +701,9 @@ __device__ __forceinline__ V3<R> light_surface(const DScene<R>& S, int material,
 }
 
 // color_at for one primary ray, recursion unrolled into a stack of pending rays
-template <class R>
+template <class R, class CNT>
 __device__ __forceinline__ V3<R> trace_pixel(const DScene<R>& S, Ray<R> primary, int max_depth, R shade_eps, int* stack,
-                                             Counters<R>& cnt, uint64_t seed, uint32_t pixel, int& hit_leaf_out) {
+                                             CNT& cnt, uint64_t seed, uint32_t pixel, int& hit_leaf_out) {
     Bounce<R> pending[RTC_MAX_BOUNCE_STACK];
     int np = 0;
     V3<R> color = mk<R>(0, 0, 0);
@@ -693,13 +713,14 @@ __device__ __forceinline__ V3<R> trace_pixel(const DScene<R>& S, Ray<R> primary,
     uint32_t ray_no = 0;
     hit_leaf_out = -1;
     while (true) {
-        NearestVisitor<R> nv(S, ray);
+        NearestVisitor<R, CNT> nv(S, ray, cnt);
         traverse(S, ray, R(0), nv, stack);
         if (ray_no == 0) hit_leaf_out = nv.leaf;
         if (nv.leaf >= 0) {
             // prepare_computations (renderer.py:206-222)
             int leaf = nv.leaf;
             R t = nv.best;
+            cnt.work(W_SHADE);
             V3<R> point = ray.o + ray.d * t;
             V3<R> normalv = normal_at(S, leaf, point, nv.u, nv.v);
             V3<R> eyev = neg(ray.d);
@@ -720,7 +741,8 @@ __device__ __forceinline__ V3<R> trace_pixel(const DScene<R>& S, Ray<R> primary,
                 V3<R> refr_dir = mk<R>(0, 0, 0);
                 if (transparency != R(0)) {
                     // n1 / n2 (renderer.py:224-242) via the order-free container pass
-                    ContainerVisitor<R> cv(S, ray, t, leaf);
+                    cnt.work(W_CONTAINER);
+                    ContainerVisitor<R, CNT> cv(S, ray, t, leaf, cnt);
                     traverse(S, ray, -inf_<R>(), cv, stack);
                     R ri_x = m[9];
                     R ri_y = cv.y_leaf >= 0 ? S.mat[10 * (size_t)S.leaf_material[cv.y_leaf] + 9] : R(1);

@@ -1,0 +1,26 @@
+"""The CPU oracle against fixtures rendered by the reference itself (oracle/make_golden.py ran
+the reference's color_at / hit(intersect_world) in the build container).  This is what pins
+the oracle: every scene family of BASELINE.json, colour to 1e-9 and the primary hit's leaf."""
+import numpy as np
+import pytest
+
+from conftest import load_golden, load_pack
+
+SCENES = ["cover", "csg_test", "group", "checkered_sphere", "checkered_plane", "checkered_cylinder",
+          "align_check_plane", "checkered_cube", "earth", "skybox", "shadow_glamour_shot_nojitter", "teapot", "dragons"]
+
+
+@pytest.mark.parametrize("name", SCENES)
+def test_oracle_matches_reference(name, oracle_cls):
+    g = load_golden(name)
+    cam, world, _ = load_pack(name, (g["meta"]["hsize"], g["meta"]["vsize"]))
+    rgb, leaf, t, rays = oracle_cls(world).render_pixels(cam, g["px"], g["py"], remaining=g["meta"]["remaining"])
+    assert rays[0] == len(g["px"])
+    # colour: the reference's own arithmetic is fp64 numpy; agreement is to rounding
+    np.testing.assert_allclose(rgb, g["rgb"], rtol=0, atol=1e-9)
+    # hit ids: exact, except where two leaves are hit at the same t (the reference's order there is set-iteration order)
+    hit = g["hit_leaf"] >= 0
+    np.testing.assert_array_equal(leaf >= 0, hit)
+    np.testing.assert_allclose(t[hit], g["hit_t"][hit], rtol=1e-9, atol=1e-12)
+    mism = leaf != g["hit_leaf"]
+    assert mism.mean() <= 0.002, "hit-leaf mismatches: %d of %d" % (mism.sum(), mism.size)

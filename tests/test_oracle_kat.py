@@ -1,0 +1,382 @@
+"""Known-answer tests the reference keeps in its doctests, restated against the CPU oracle
+(and, for the host-only pieces, against this package's front-end).  Each test cites the
+reference docstring it restates.  Together with tests/test_oracle_golden.py this is what
+"the oracle is pinned" means."""
+import numpy as np
+import pytest
+
+from ray_tracer_challenge_amd import shapes as S
+from ray_tracer_challenge_amd.canvas import canvas, color, construct_ppm, write_pixel
+from ray_tracer_challenge_amd.matrix import (inverse, matrix, matrix_multiply, rotation_y, scaling, translation)
+from ray_tracer_challenge_amd.renderer import (World, camera, default_world, point_light, view_transform)
+from ray_tracer_challenge_amd.vector import normalize, point, vector
+
+R2 = np.sqrt(2) / 2
+
+
+def close(a, b, atol=1e-5):
+    return np.allclose(np.asarray(getattr(a, "arr", a), float)[:3], np.asarray(getattr(b, "arr", b), float)[:3], atol=atol)
+
+
+def world_of(*shapes, light=None):
+    return World([light or point_light(point(-10, 10, -10), color(1, 1, 1))], list(shapes))
+
+
+# ---------------------------------------------------------------- camera / rays (host + oracle)
+def test_camera_pixel_size():          # renderer.py:705-711
+    assert np.isclose(camera(200, 125, np.pi / 2).pixel_size, 0.01)
+    assert np.isclose(camera(125, 200, np.pi / 2).pixel_size, 0.01)
+
+
+def test_view_transform():             # renderer.py:615-648
+    assert view_transform(point(0, 0, 0), point(0, 0, -1), vector(0, 1, 0)).compare(matrix(*np.eye(4).ravel()))
+    assert view_transform(point(0, 0, 0), point(0, 0, 1), vector(0, 1, 0)).compare(scaling(-1, 1, -1))
+    assert view_transform(point(0, 0, 8), point(0, 0, 0), vector(0, 1, 0)).compare(translation(0, 0, -8))
+    t = view_transform(point(1, 3, 2), point(4, -2, 8), vector(1, 1, 0))
+    want = [[-5.07092553e-01, 5.07092553e-01, 6.76123404e-01, -2.36643191e+00],
+            [7.67715934e-01, 6.06091527e-01, 1.21218305e-01, -2.82842712e+00],
+            [-3.58568583e-01, 5.97614305e-01, -7.17137166e-01, 0.0], [0, 0, 0, 1]]
+    assert np.allclose(t.arr, want, atol=1e-8)
+
+
+def test_ray_for_pixel(oracle_cls):    # renderer.py:717-740
+    o = oracle_cls(default_world())
+    c = camera(201, 101, np.pi / 2)
+    org, d = o.ray_for_pixel(c, 100, 50)
+    assert close(org, [0, 0, 0]) and close(d, [0, 0, -1])
+    org, d = o.ray_for_pixel(c, 0, 0)
+    assert close(org, [0, 0, 0]) and close(d, [0.66519, 0.33259, -0.66851])
+    c.transform = matrix_multiply(rotation_y(np.pi / 4), translation(0, -2, 5))
+    org, d = o.ray_for_pixel(c, 100, 50)
+    assert close(org, [0, 2, -5]) and close(d, [R2, 0, -R2])
+
+
+def test_render_centre_pixel(oracle_cls):   # renderer.py:755-763
+    c = camera(11, 11, np.pi / 2)
+    c.transform = view_transform(point(0, 0, -5), point(0, 0, 0), vector(0, 1, 0))
+    rgb, ids, _ = oracle_cls(default_world()).render(c)
+    assert np.allclose(rgb[5, 5], [0.38066119, 0.47582649, 0.28549589])
+
+
+# ---------------------------------------------------------------- intersect_world / color_at / shade_hit
+def test_intersect_world(oracle_cls):  # renderer.py:69-73
+    t, _ = oracle_cls(default_world()).intersect_world([0, 0, -5], [0, 0, 1])
+    assert list(t) == [4, 4.5, 5.5, 6]
+
+
+def test_color_at(oracle_cls):         # renderer.py:566-586
+    w = default_world()
+    assert np.allclose(oracle_cls(w).color_at([0, 0, -5], [0, 1, 0]), 0)
+    assert np.allclose(oracle_cls(w).color_at([0, 0, -5], [0, 0, 1]), [0.38066, 0.47583, 0.28549589], atol=1e-5)
+    w.contains[0].material.ambient = np.float64(1.0)
+    w.contains[1].material.ambient = np.float64(1.0)
+    assert np.allclose(oracle_cls(w).color_at([0, 0, 0.75], [0, 0, -1]), w.contains[1].material.color)
+
+
+def test_shade_hit_inside_and_shadow(oracle_cls):   # renderer.py:420-445
+    w = default_world()
+    w.lights[0] = point_light(point(0, 0.25, 0), color(1, 1, 1))
+    assert np.allclose(oracle_cls(w).color_at([0, 0, 0], [0, 0, 1]), 0.90498, atol=1e-5)
+    s1, s2 = S.sphere(), S.sphere()
+    s2.transform = translation(0, 0, 10)
+    w = World([point_light(point(0, 0, -1), color(1, 1, 1))], [s1, s2])
+    assert np.allclose(oracle_cls(w).color_at([0, 0, 5], [0, 0, 1]), 0.1)
+
+
+def _floor_world(reflective=0.0, transparency=0.0, with_ball=False):
+    w = default_world()
+    floor = S.plane()
+    floor.transform = translation(0, -1, 0)
+    floor.material.reflective = np.float64(reflective)
+    floor.material.transparency = np.float64(transparency)
+    if transparency:
+        floor.material.refractive_index = np.float64(1.5)
+    w.contains.append(floor)
+    if with_ball:
+        ball = S.sphere()
+        ball.material.color = color(1, 0, 0)
+        ball.material.ambient = np.float64(0.5)
+        ball.transform = translation(0, -3.5, -0.5)
+        w.contains.append(ball)
+    return w
+
+
+def test_shade_hit_reflective_and_reflected_color(oracle_cls):   # renderer.py:447-461, 368-398
+    ray = ([0, 0, -3], [0, -R2, R2])
+    with_refl = oracle_cls(_floor_world(reflective=0.5)).color_at(*ray)
+    assert np.allclose(with_refl, [0.87675616, 0.92433885, 0.82917347])
+    without = oracle_cls(_floor_world(reflective=0.0)).color_at(*ray)
+    assert np.allclose(with_refl - without, [0.19033077, 0.23791346, 0.14274808])      # reflected_color
+    assert np.allclose(oracle_cls(_floor_world(reflective=0.5)).color_at(*ray, remaining=0), without)
+
+
+def test_shade_hit_transparent_and_schlick(oracle_cls):   # renderer.py:463-504
+    ray = ([0, 0, -3], [0, -R2, R2])
+    c = oracle_cls(_floor_world(transparency=0.5, with_ball=True)).color_at(*ray)
+    assert np.allclose(c, [0.93642, 0.68642539, 0.68642539], atol=1e-5)
+    c = oracle_cls(_floor_world(reflective=0.5, transparency=0.5, with_ball=True)).color_at(*ray)
+    assert np.allclose(c, [0.93391, 0.69643, 0.69243], atol=1e-5)
+
+
+def test_refracted_color(oracle_cls):  # renderer.py:318-330
+    w = default_world()
+    a, b = w.contains
+    a.material.ambient = np.float64(1.0)
+    a.material.pattern = S.test_pattern()
+    b.material.transparency = np.float64(1.0)
+    b.material.refractive_index = np.float64(1.5)
+    # silence B's own surface term so that color_at == refracted_color of the doctest
+    b.material.ambient = b.material.diffuse = b.material.specular = np.float64(0.0)
+    o = oracle_cls(w)
+    t, _ = o.intersect_world([0, 0, 0.1], [0, 1, 0])
+    # the doctest feeds hand-rounded t's (+-0.4899 for B); the traced ones agree to 1e-5
+    assert len(t) == 4 and np.allclose(t[1:3], [-0.4899, 0.4899], atol=1e-5)
+    assert np.allclose(o.color_at([0, 0, 0.1], [0, 1, 0]), [0.0, 0.99888367, 0.04721668], atol=2e-4)
+    assert np.allclose(o.color_at([0, 0, 0.1], [0, 1, 0], remaining=0), 0)            # renderer.py:303-305
+
+
+def test_n1_n2(oracle_cls):            # renderer.py:162-192
+    A, B, C = S.glass_sphere(), S.glass_sphere(), S.glass_sphere()
+    A.transform = scaling(2, 2, 2)
+    B.transform = translation(0, 0, -0.25)
+    B.material.refractive_index = np.float64(2.0)
+    C.transform = translation(0, 0, 0.25)
+    C.material.refractive_index = np.float64(2.5)
+    o = oracle_cls(world_of(A, B, C))
+    t, _ = o.intersect_world([0, 0, -4], [0, 0, 1])
+    assert np.allclose(t, [2, 2.75, 3.25, 4.75, 5.25, 6])
+    want = [(1.0, 1.5), (1.5, 2.0), (2.0, 2.5), (2.5, 2.5), (2.5, 1.5), (1.5, 1.0)]
+    for k, (n1, n2) in enumerate(want):
+        c = o.prepare_computations([0, 0, -4], [0, 0, 1], k)
+        assert (c["n1"], c["n2"]) == (n1, n2)
+
+
+def test_prepare_computations(oracle_cls):   # renderer.py:100-159, 194-204
+    s = S.sphere()
+    o = oracle_cls(world_of(s))
+    c = o.prepare_computations([0, 0, -5], [0, 0, 1], 0)
+    assert c["t"] == 4 and close(c["point"], [0, 0, -1]) and close(c["eyev"], [0, 0, -1]) and close(c["normalv"], [0, 0, -1])
+    assert not c["inside"]
+    c = o.prepare_computations([0, 0, 0], [0, 0, 1], 1)
+    assert c["inside"] and close(c["point"], [0, 0, 1]) and close(c["normalv"], [0, 0, -1])
+    s = S.glass_sphere()
+    s.transform = translation(0, 0, 1)
+    c = oracle_cls(world_of(s)).prepare_computations([0, 0, -5], [0, 0, 1], 0)
+    assert c["t"] == 5
+    assert c["over_point"][2] < -1e-6 / 2 and c["point"][2] > c["over_point"][2]
+    assert c["under_point"][2] > 1e-6 / 2 and c["point"][2] < c["under_point"][2]
+    p = S.plane()
+    c = oracle_cls(world_of(p)).prepare_computations([0, 1, -1], [0, -R2, R2], 0)
+    assert close(c["reflectv"], [0, R2, R2])
+
+
+def test_schlick(oracle_cls):          # renderer.py:248-270
+    o = oracle_cls(world_of(S.glass_sphere()))
+    assert o.prepare_computations([0, 0, R2], [0, 1, 0], 1)["schlick"] == 1.0
+    assert np.isclose(o.prepare_computations([0, 0, 0], [0, 1, 0], 1)["schlick"], 0.04)
+    # the doctest feeds the hand-rounded t = 1.8589; the traced hit gives 0.488814
+    assert np.isclose(o.prepare_computations([0, 0.99, -2], [0, 0, 1], 0)["schlick"], 0.48873, atol=2e-4)
+
+
+def test_is_shadowed(oracle_cls):      # renderer.py:530-548
+    o = oracle_cls(default_world())
+    light = [-10, 10, -10]
+    assert not o.is_shadowed(light, [0, 10, 0])
+    assert o.is_shadowed(light, [10, -10, 10])
+    assert not o.is_shadowed(light, [-20, 20, -20])
+    assert not o.is_shadowed(light, [-2, 2, -2])
+
+
+def test_lighting(oracle_cls):         # renderer.py:992-1064
+    s = S.sphere()
+    m = s.material
+
+    def lit(light_pos, eye, intensity=1.0, p=(0, 0, 0)):
+        w = world_of(s, light=point_light(point(*light_pos), color(1, 1, 1)))
+        return oracle_cls(w).lighting(m, s, 0, p, eye, [0, 0, -1], intensity)
+    assert np.allclose(lit((0, 0, -10), [0, 0, -1]), 1.9)
+    assert np.allclose(lit((0, 0, -10), [0, R2, -R2]), 1.0)
+    assert np.allclose(lit((0, 10, -10), [0, 0, -1]), 0.7364, atol=1e-4)
+    assert np.allclose(lit((0, 10, -10), [0, -R2, -R2]), 1.6364, atol=1e-4)
+    assert np.allclose(lit((0, 0, 10), [0, 0, -1]), 0.1)
+    assert np.allclose(lit((0, 0, -10), [0, 0, -1], intensity=0.0), 0.1)
+    m.pattern = S.stripe_pattern(color(1, 1, 1), color(0, 0, 0))
+    m.ambient, m.diffuse, m.specular = np.float64(1), np.float64(0), np.float64(0)
+    assert np.allclose(lit((0, 0, -10), [0, 0, -1], p=(0.9, 0, 0)), 1)
+    assert np.allclose(lit((0, 0, -10), [0, 0, -1], p=(1.1, 0, 0)), 0)
+
+
+# ---------------------------------------------------------------- primitives
+def test_sphere_intersections(oracle_cls):   # shapes.py:1301-1358
+    s = S.sphere()
+    o = oracle_cls(world_of(s))
+    assert list(o.intersect(s, [0, 0, -5], [0, 0, 1])[0]) == [4.0, 6.0]
+    assert list(o.intersect(s, [0, 1, -5], [0, 0, 1])[0]) == [5.0, 5.0]
+    assert len(o.intersect(s, [0, 2, -5], [0, 0, 1])[0]) == 0
+    assert list(o.intersect(s, [0, 0, 0], [0, 0, 1])[0]) == [-1.0, 1.0]
+    assert list(o.intersect(s, [0, 0, 5], [0, 0, 1])[0]) == [-6.0, -4.0]
+    s2 = S.sphere()
+    s2.transform = scaling(2, 2, 2)
+    assert list(oracle_cls(world_of(s2)).intersect(s2, [0, 0, -5], [0, 0, 1])[0]) == [3, 7]
+    s3 = S.sphere()
+    s3.transform = translation(5, 0, 0)
+    assert len(oracle_cls(world_of(s3)).intersect(s3, [0, 0, -5], [0, 0, 1])[0]) == 0
+
+
+def test_plane(oracle_cls):            # shapes.py:1201-1234
+    p = S.plane()
+    o = oracle_cls(world_of(p))
+    for pt in ([0, 0, 0], [10, 0, -10], [-5, 0, 150]):
+        assert close(o.normal_at(p, pt), [0, 1, 0])
+    assert len(o.intersect(p, [0, 10, 0], [0, 0, 1])[0]) == 0
+    assert len(o.intersect(p, [0, 0, 0], [0, 0, 1])[0]) == 0
+    assert np.allclose(o.intersect(p, [0, 1, 0], [0, -1, 0])[0], [1])
+    assert np.allclose(o.intersect(p, [0, -1, 0], [0, 1, 0])[0], [1])
+
+
+def test_cube(oracle_cls):             # shapes.py:1149-1195
+    c = S.cube()
+    o = oracle_cls(world_of(c))
+    hits = [((5, 0.5, 0), (-1, 0, 0), 4, 6), ((-5, 0.5, 0), (1, 0, 0), 4, 6), ((0.5, 5, 0), (0, -1, 0), 4, 6),
+            ((0.5, -5, 0), (0, 1, 0), 4, 6), ((0.5, 0, 5), (0, 0, -1), 4, 6), ((0.5, 0, -5), (0, 0, 1), 4, 6),
+            ((0, 0.5, 0), (0, 0, 1), -1, 1)]
+    for org, d, t1, t2 in hits:
+        assert list(o.intersect(c, org, d)[0]) == [t1, t2]
+    misses = [((-2, 0, 0), (0.2673, 0.5345, 0.8018)), ((0, -2, 0), (0.8018, 0.2673, 0.5345)),
+              ((0, 0, -2), (0.5345, 0.8018, 0.2673)), ((2, 0, 2), (0, 0, -1)), ((0, 2, 2), (0, -1, 0)), ((2, 2, 0), (-1, 0, 0))]
+    for org, d in misses:
+        assert len(o.intersect(c, org, d)[0]) == 0
+    normals = [((1, 0.5, -0.8), (1, 0, 0)), ((-1, -0.2, 0.9), (-1, 0, 0)), ((-0.4, 1, -0.1), (0, 1, 0)),
+               ((0.3, -1, -0.7), (0, -1, 0)), ((-0.6, 0.3, 1), (0, 0, 1)), ((0.4, 0.4, -1), (0, 0, -1)),
+               ((1, 1, 1), (1, 0, 0)), ((-1, -1, -1), (-1, 0, 0))]
+    for p, n in normals:
+        assert close(o.normal_at(c, p), n)
+
+
+def test_cylinder(oracle_cls):         # shapes.py:1046-1143
+    cyl = S.cylinder()
+    o = oracle_cls(world_of(cyl))
+    for org, d in [((1, 0, 0), (0, 1, 0)), ((0, 0, 0), (0, 1, 0)), ((0, 0, -5), (1, 1, 1))]:
+        assert len(o.intersect(cyl, org, normalize(vector(*d)))[0]) == 0
+    for org, d, t0, t1 in [((1, 0, -5), (0, 0, 1), 5, 5), ((0, 0, -5), (0, 0, 1), 4, 6),
+                           ((0.5, 0, -5), (0.1, 1, 1), 6.80798191702732, 7.088723439378861)]:
+        assert np.allclose(o.intersect(cyl, org, normalize(vector(*d)))[0], [t0, t1])
+    for p, n in [((1, 0, 0), (1, 0, 0)), ((0, 5, -1), (0, 0, -1)), ((0, -2, 1), (0, 0, 1)), ((-1, 1, 0), (-1, 0, 0))]:
+        assert close(o.normal_at(cyl, p), n)
+    assert cyl.minimum == -np.inf and cyl.maximum == np.inf and not cyl.closed
+    cyl = S.cylinder()
+    cyl.minimum, cyl.maximum = 1.0, 2.0
+    o = oracle_cls(world_of(cyl))
+    for org, d, n in [((0, 1.5, 0), (0.1, 1, 0), 0), ((0, 3, -5), (0, 0, 1), 0), ((0, 0, -5), (0, 0, 1), 0),
+                      ((0, 2, -5), (0, 0, 1), 0), ((0, 1, -5), (0, 0, 1), 0), ((0, 1.5, -2), (0, 0, 1), 2)]:
+        assert len(o.intersect(cyl, org, normalize(vector(*d)))[0]) == n
+    cyl = S.cylinder()
+    cyl.minimum, cyl.maximum, cyl.closed = 1.0, 2.0, True
+    o = oracle_cls(world_of(cyl))
+    for org, d in [((0, 3, 0), (0, -1, 0)), ((0, 3, -2), (0, -1, 2)), ((0, 4, -2), (0, -1, 1)),
+                   ((0, 0, -2), (0, 1, 2)), ((0, -1, -2), (0, 1, 1))]:
+        assert len(o.intersect(cyl, org, normalize(vector(*d)))[0]) == 2
+    for p, n in [((0, 1, 0), (0, -1, 0)), ((0.5, 1, 0), (0, -1, 0)), ((0, 1, 0.5), (0, -1, 0)),
+                 ((0, 2, 0), (0, 1, 0)), ((0.5, 2, 0), (0, 1, 0)), ((0, 2, 0.5), (0, 1, 0))]:
+        assert close(o.normal_at(cyl, p), n)
+
+
+def test_cone(oracle_cls):             # shapes.py:995-1040
+    shape = S.cone()
+    o = oracle_cls(world_of(shape))
+    for org, d, t0, t1 in [((0, 0, -5), (0, 0, 1), 5, 5), ((0, 0, -5), (1, 1, 1), 8.66025, 8.66025),
+                           ((1, 1, -5), (-0.5, -1, 1), 4.55006, 49.44994)]:
+        assert np.allclose(o.intersect(shape, org, normalize(vector(*d)))[0], [t0, t1], atol=1e-4)
+    t, _ = o.intersect(shape, [0, 0, -1], normalize(vector(0, 1, 1)))
+    assert len(t) == 1 and np.isclose(t[0], 0.35355, atol=1e-5)
+    shape = S.cone()
+    shape.minimum, shape.maximum, shape.closed = -0.5, 0.5, True
+    o = oracle_cls(world_of(shape))
+    for org, d, n in [((0, 0, -5), (0, 1, 0), 0), ((0, 0, -0.25), (0, 1, 1), 2), ((0, 0, -0.25), (0, 1, 0), 4)]:
+        assert len(o.intersect(shape, org, normalize(vector(*d)))[0]) == n
+    shape = S.cone()
+    o = oracle_cls(world_of(shape))
+    # local normals (1, -sqrt2, 1) and (-1, 1, 0), normalised by normal_at
+    assert close(o.normal_at(shape, [1, 1, 1]), np.array([1, -np.sqrt(2), 1]) / 2)
+    assert close(o.normal_at(shape, [-1, -1, 0]), np.array([-1, 1, 0]) / np.sqrt(2))
+
+
+def test_triangle_fields():            # shapes.py:899-905
+    t = S.triangle(point(0, 1, 0), point(-1, 0, 0), point(1, 0, 0))
+    assert t.e1.compare(vector(-1, -1, 0)) and t.e2.compare(vector(1, -1, 0))
+
+
+def test_triangle_normal(oracle_cls):  # shapes.py:904 (t.normal == (0,0,-1))
+    t = S.triangle(point(0, 1, 0), point(-1, 0, 0), point(1, 0, 0))
+    assert close(oracle_cls(world_of(t)).normal_at(t, [0, 0.5, 0]), [0, 0, -1])
+
+
+def test_groups(oracle_cls):           # shapes.py:931-989
+    g = S.group()
+    s1, s2, s3 = S.sphere(), S.sphere(), S.sphere()
+    s2.transform = translation(0, 0, -3)
+    s3.transform = translation(5, 0, 0)
+    g.add_child([s1, s2, s3])
+    o = oracle_cls(world_of(g))
+    t, nodes = o.intersect(g, [0, 0, -5], [0, 0, 1])
+    want = [o.ex.node_of(x) for x in (s2, s2, s1, s1)]
+    assert len(t) == 4 and list(nodes) == want
+    g = S.group()
+    g.transform = scaling(2, 2, 2)
+    s = S.sphere()
+    s.transform = translation(5, 0, 0)
+    g.add_child(s)
+    assert len(oracle_cls(world_of(g)).intersect(g, [10, 0, -10], [0, 0, 1])[0]) == 2
+    g1, g2 = S.group(), S.group()
+    g1.transform = rotation_y(np.pi / 2)
+    g2.transform = scaling(1, 2, 3)
+    g1.add_child(g2)
+    s = S.sphere()
+    s.transform = translation(5, 0, 0)
+    g2.add_child(s)
+    n = oracle_cls(world_of(g1)).normal_at(s, [1.7321, 1.1547, -5.5774])
+    assert close(n, [0.28570368, 0.42854315, -0.85716053], atol=1e-7)
+
+
+def test_pattern_transforms(oracle_cls):   # shapes.py:1618-1661
+    def at(shape_xf, pat, pat_xf, p):
+        s = S.sphere()
+        if shape_xf is not None:
+            s.transform = shape_xf
+        if pat_xf is not None:
+            pat.transform = pat_xf
+        s.material.pattern = pat
+        return oracle_cls(world_of(s)).pattern_at_shape(pat, s, p)
+    W, B = color(1, 1, 1), color(0, 0, 0)
+    assert np.allclose(at(scaling(2, 2, 2), S.stripe_pattern(W, B), None, [1.5, 0, 0]), 1)
+    assert np.allclose(at(None, S.stripe_pattern(W, B), scaling(2, 2, 2), [1.5, 0, 0]), 1)
+    assert np.allclose(at(scaling(2, 2, 2), S.stripe_pattern(W, B), translation(0.5, 0, 0), [1.5, 0, 0]), 1)
+    assert np.allclose(at(scaling(2, 2, 2), S.test_pattern(), None, [2, 3, 4]), [1, 1.5, 2])
+    assert np.allclose(at(None, S.test_pattern(), scaling(2, 2, 2), [2, 3, 4]), [1, 1.5, 2])
+    assert np.allclose(at(scaling(2, 2, 2), S.test_pattern(), translation(0.5, 1, 1.5), [2.5, 3, 3.5]), [0.75, 0.5, 0.25])
+
+
+# ---------------------------------------------------------------- host-only pieces of the boundary
+def test_ppm_bytes():                  # canvas.py:159-176
+    ca = canvas(5, 3)
+    write_pixel(ca, 0, 0, color(1.5, 0, 0))
+    write_pixel(ca, 2, 1, color(0, 0.5, 0))
+    write_pixel(ca, 4, 2, color(-0.5, 0, 1))
+    ppm = construct_ppm(ca)
+    assert ppm.startswith(b"P6\n5 3\n255\n")
+    body = ppm[len(b"P6\n5 3\n255\n"):]
+    want = bytearray(45)
+    want[0], want[22], want[44] = 0xFF, 0x80, 0xFF
+    assert body == bytes(want) + b"\n"
+    assert construct_ppm(canvas(64, 64))[-1] == 10
+
+
+def test_matrix_inverse():             # matrix.py:352-376
+    b = inverse(matrix(-5, 2, 6, -8, 1, -5, 1, 8, 7, 7, -6, -7, 1, -3, 7, 4))
+    want = [[0.21804511, 0.45112782, 0.2406015, -0.04511278], [-0.80827068, -1.45676692, -0.44360902, 0.52067669],
+            [-0.07894737, -0.22368421, -0.05263158, 0.19736842], [-0.52255639, -0.81390977, -0.30075188, 0.30639098]]
+    assert np.allclose(b.arr, want, atol=1e-8)
+    b = inverse(matrix(9, 3, 0, 9, -5, -2, -6, -3, -4, 9, 6, 4, -7, 6, 6, 2))
+    assert np.allclose(b.arr[2], [-0.02901235, -0.1462963, -0.10925926, 0.12962963], atol=1e-8)
+    with pytest.raises(ValueError):
+        inverse(matrix(-4, 2, -2, -3, 9, 6, 2, 6, 0, -5, 1, -5, 0, 0, 0, 0))

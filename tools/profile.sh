@@ -1,0 +1,14 @@
+#!/bin/bash
+# Runs on the GPU box (via gpurun): kernel-trace stats of the default bench, then HBM PMC passes.
+# Usage: tools/profile.sh <round tag>
+set -o pipefail
+TAG=${1:-r01}
+OUT=gpurun_out/prof_$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+REPO=$GRAFT_REPO_ROOT
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $REPO/$OUT/kt -o kt -- python3 $REPO/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $REPO/$OUT/bench_under_rocprof.json 2> $REPO/$OUT/kt.err || exit 1
+timeout -s KILL 240 rocprofv3 --pmc FETCH_SIZE -d $REPO/$OUT/pmc_fetch -o pmc -- python3 $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> $REPO/$OUT/pmc_fetch.err || exit 1
+timeout -s KILL 240 rocprofv3 --pmc WRITE_SIZE -d $REPO/$OUT/pmc_write -o pmc -- python3 $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> $REPO/$OUT/pmc_write.err || exit 1
+timeout -s KILL 240 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY -d $REPO/$OUT/pmc_sq -o pmc -- python3 $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> $REPO/$OUT/pmc_sq.err || exit 1
+find $REPO/$OUT -name "*.csv" | head -30
