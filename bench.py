@@ -86,41 +86,20 @@ def main():
     scene = _ffi.Scene(cs, device=local_rank)
     info = scene.info()
 
-    T = 32
-    tx, ty = _ffi.tiles_for(cam.hsize, cam.vsize, T)
-    all_tiles = np.arange(tx * ty, dtype=np.int32)
-    mine = all_tiles[rank::world]
-    per_rank = (len(all_tiles) + world - 1) // world          # gather needs equal-sized pieces
-    tiles_dev = torch.from_numpy(mine.copy()).to(dev)
-    compact = torch.zeros((per_rank, T, T, 3), dtype=torch.float64, device=dev)
+    from ray_tracer_challenge_amd.dist import TILE as T, FrameGather, render_distributed
+    fg = FrameGather(cam.hsize, cam.vsize, world, rank, dev, T)
+    mine = fg.mine
     rays_dev = torch.zeros(12, dtype=torch.int64, device=dev)
-    frame = torch.zeros((cam.hsize, cam.vsize, 3), dtype=torch.float64, device=dev) if rank == 0 else None
-    gathered = [torch.zeros_like(compact) for _ in range(world)] if (rank == 0 and world > 1) else None
-    # destination (x, y) of every compact pixel of every rank, for the un-permute on rank 0
-    if rank == 0:
-        slots = np.concatenate([np.pad(all_tiles[r::world], (0, per_rank - len(all_tiles[r::world])), constant_values=-1)
-                                for r in range(world)])
-        ly, lx = np.meshgrid(np.arange(T), np.arange(T), indexing="ij")
-        gx = (slots[:, None, None] % tx) * T + lx[None]
-        gy = (slots[:, None, None] // tx) * T + ly[None]
-        ok = (slots[:, None, None] >= 0) & (gx < cam.hsize) & (gy < cam.vsize)
-        dst = torch.from_numpy((gx * cam.vsize + gy)[ok].astype(np.int64)).to(dev)
-        src = torch.from_numpy(np.nonzero(ok.ravel())[0].astype(np.int64)).to(dev)
+    frame = fg.frame
 
     def step(precision, count_work=False):
         stream = torch.cuda.current_stream().cuda_stream
         if world == 1:
-            # whole frame straight into the canvas layout
+            # whole frame straight into the canvas layout: no tile list, no gather
             scene.render_device(cam, frame.data_ptr(), rays_ptr=rays_dev.data_ptr(), precision=precision,
                                 max_depth=args.depth, tile_size=T, stream=stream, count_work=count_work)
             return
-        scene.render_device(cam, compact.data_ptr(), rays_ptr=rays_dev.data_ptr(), tile_ids_ptr=tiles_dev.data_ptr(),
-                            n_tiles=len(mine), precision=precision, max_depth=args.depth, tile_size=T, stream=stream,
-                            count_work=count_work)
-        dist.gather(compact, gathered, dst=0)
-        if rank == 0:
-            flat = torch.cat([g.reshape(-1, 3) for g in gathered], dim=0)
-            frame.view(-1, 3).index_copy_(0, dst, flat.index_select(0, src))
+        render_distributed(scene, cam, fg, precision, args.depth, rays_dev.data_ptr(), stream, count_work)
 
     def sync():
         torch.cuda.synchronize()
@@ -157,7 +136,7 @@ def main():
             if world == 1:
                 scene.render_device(cam, frame.data_ptr(), precision=precision, max_depth=args.depth, tile_size=T, stream=stream)
             else:
-                scene.render_device(cam, compact.data_ptr(), tile_ids_ptr=tiles_dev.data_ptr(), n_tiles=len(mine),
+                scene.render_device(cam, fg.compact.data_ptr(), tile_ids_ptr=fg.tiles_dev.data_ptr(), n_tiles=len(mine),
                                     precision=precision, max_depth=args.depth, tile_size=T, stream=stream)
         e1.record()
         torch.cuda.synchronize()

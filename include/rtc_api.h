@@ -141,7 +141,9 @@ typedef struct {
     int32_t max_depth;   /* the reference's `remaining`, default 5 (renderer.py:562) */
     int32_t tile_size;   /* pixels per tile edge for rtc_render_tiles*; multiple of 8; 0 -> 32 */
     int32_t flags;       /* RTC_FLAG_* */
-    double shade_eps;    /* over/under-point offset; <= 0 -> 1e-6 in fp64 (renderer.py:15, :221-222), 2e-4 in fp32 */
+    double shade_eps;    /* over/under-point offset (renderer.py:15, :221-222); <= 0 -> 1e-6 in fp64, 1e-5 in fp32 */
+    double shade_eps_rel; /* the offset actually used is max(shade_eps, shade_eps_rel * max|coordinate of hit point or ray origin|);
+                            < 0 -> default: 0 in fp64 (the reference's fixed EPSILON), 1e-6 (~8 ulp) in fp32 */
     uint64_t seed;       /* jittered area lights only */
 } rtc_render_opts;
 

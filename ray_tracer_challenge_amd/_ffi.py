@@ -44,7 +44,7 @@ class CameraDesc(C.Structure):
 
 class RenderOpts(C.Structure):
     _fields_ = [("precision", C.c_int32), ("max_depth", C.c_int32), ("tile_size", C.c_int32),
-                ("flags", C.c_int32), ("shade_eps", C.c_double), ("seed", C.c_uint64)]
+                ("flags", C.c_int32), ("shade_eps", C.c_double), ("shade_eps_rel", C.c_double), ("seed", C.c_uint64)]
 
 
 class Stats(C.Structure):
@@ -64,12 +64,34 @@ class RtcError(RuntimeError):
     pass
 
 
+def _preload_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64 (SONAME
+    libamdhip64.so.7, found through torch/lib's RPATH under the unversioned name), librtc_hip.so
+    asks for libamdhip64.so.7: if ours came first the loader would map BOTH copies and the second
+    runtime sees no GPU.  Loading torch's copy first (when torch is installed) makes either
+    import order end with a single runtime; without torch the system one in /opt/rocm is used."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(path):
+        try:
+            C.CDLL(path, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def lib():
     global _lib
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise RtcError("librtc_hip.so is not built (run `python -c 'import __graft_entry__ as g; g.build()'` "
                            "or `make -C ray_tracer_challenge_amd/csrc`); there is no CPU fallback")
+        _preload_hip_runtime()
         L = C.CDLL(LIB_PATH)
         L.rtc_last_error.restype = C.c_char_p
         L.rtc_scene_create.argtypes = [C.POINTER(SceneDesc), C.c_int, C.POINTER(_P)]
@@ -105,11 +127,11 @@ def make_camera(cam):
     return c
 
 
-def make_opts(precision="fp64", max_depth=5, tile_size=32, shade_eps=0.0, seed=0, count_work=False):
+def make_opts(precision="fp64", max_depth=5, tile_size=32, shade_eps=0.0, seed=0, count_work=False, shade_eps_rel=-1.0):
     bits = {"fp64": 64, "fp32": 32, 64: 64, 32: 32}.get(precision)
     if bits is None:
         raise ValueError("precision must be 'fp64' or 'fp32'")
-    return RenderOpts(bits, int(max_depth), int(tile_size), 1 if count_work else 0, float(shade_eps), int(seed))
+    return RenderOpts(bits, int(max_depth), int(tile_size), 1 if count_work else 0, float(shade_eps), float(shade_eps_rel), int(seed))
 
 
 def make_desc(cs):

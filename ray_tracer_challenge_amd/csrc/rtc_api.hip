@@ -37,7 +37,7 @@ int fail(int code, const char* fmt, ...) {
 // kernels
 // ---------------------------------------------------------------------------------------------
 template <class R, bool PROF>
-__global__ __launch_bounds__(RTC_BLOCK) void trace_kernel(rtc::DScene<R> S, rtc::DCamera<R> cam, rtc::DFrame F, R shade_eps) {
+__global__ __launch_bounds__(RTC_BLOCK) void trace_kernel(rtc::DScene<R> S, rtc::DCamera<R> cam, rtc::DFrame F, R shade_eps, R shade_eps_rel) {
     __shared__ int s_stack[RTC_BVH_STACK * RTC_BLOCK];
     int* stack = s_stack + threadIdx.x;
     const int T = F.tile_size, per_tile = T * T, sub = T / 8;
@@ -55,7 +55,7 @@ __global__ __launch_bounds__(RTC_BLOCK) void trace_kernel(rtc::DScene<R> S, rtc:
             rtc::Ray<R> ray = rtc::ray_for_pixel(cam, x, y);
             cnt.c[0] = 1;
             int hit_leaf;
-            rtc::V3<R> c = rtc::trace_pixel(S, ray, F.max_depth, shade_eps, stack, cnt, F.seed,
+            rtc::V3<R> c = rtc::trace_pixel(S, ray, F.max_depth, shade_eps, shade_eps_rel, stack, cnt, F.seed,
                                             (uint32_t)(y * cam.hsize + x), hit_leaf);
             size_t o;
             if (F.tile_ids) {
@@ -358,7 +358,7 @@ template <class R> rtc::DCamera<R> make_camera(const rtc_camera& c) {
 }
 
 int check_render_args(const rtc_scene* scene, const rtc_camera* cam, const rtc_render_opts* opts, int* tile_size, int* precision,
-                      int* depth, double* eps) {
+                      int* depth, double* eps, double* eps_rel) {
     if (!scene || !cam) return fail(RTC_ERR_INVALID, "null scene or camera");
     if (cam->hsize < 1 || cam->vsize < 1 || (long long)cam->hsize * cam->vsize > (1LL << 30))
         return fail(RTC_ERR_INVALID, "bad image size %d x %d", cam->hsize, cam->vsize);
@@ -369,15 +369,16 @@ int check_render_args(const rtc_scene* scene, const rtc_camera* cam, const rtc_r
     if (*depth < 0 || *depth > RTC_MAX_BOUNCE_STACK - 2) return fail(RTC_ERR_LIMIT, "max_depth %d outside 0..%d", *depth, RTC_MAX_BOUNCE_STACK - 2);
     *tile_size = (opts && opts->tile_size) ? opts->tile_size : 32;
     if (*tile_size < 8 || *tile_size % 8 || *tile_size > 1024) return fail(RTC_ERR_INVALID, "tile_size must be a multiple of 8 in 8..1024");
-    *eps = (opts && opts->shade_eps > 0) ? opts->shade_eps : (*precision == 64 ? 0.000001 : 0.0002);
+    *eps = (opts && opts->shade_eps > 0) ? opts->shade_eps : (*precision == 64 ? 0.000001 : 0.00001);
+    *eps_rel = (opts && opts->shade_eps_rel >= 0) ? opts->shade_eps_rel : (*precision == 64 ? 0.0 : 0.000001);
     return 0;
 }
 
 int launch(rtc_scene* scene, const rtc_camera* cam, const rtc_render_opts* opts, int32_t n_tiles, const int32_t* tile_ids_dev,
            double* rgb_dev, int32_t* hit_id_dev, int64_t* rays_dev, int64_t* work_dev, hipStream_t stream) {
     int T, precision, depth;
-    double eps;
-    if (int rc = check_render_args(scene, cam, opts, &T, &precision, &depth, &eps)) return rc;
+    double eps, eps_rel;
+    if (int rc = check_render_args(scene, cam, opts, &T, &precision, &depth, &eps, &eps_rel)) return rc;
     if (!rgb_dev) return fail(RTC_ERR_INVALID, "null output buffer");
     int tiles_x = (cam->hsize + T - 1) / T, tiles_y = (cam->vsize + T - 1) / T;
     if (!tile_ids_dev) n_tiles = tiles_x * tiles_y;
@@ -394,11 +395,11 @@ int launch(rtc_scene* scene, const rtc_camera* cam, const rtc_render_opts* opts,
     F.work = reinterpret_cast<unsigned long long*>(work_dev);
     dim3 grid((unsigned)blocks), block(RTC_BLOCK);
     if (precision == 64) {
-        if (work_dev) hipLaunchKernelGGL((trace_kernel<double, true>), grid, block, 0, stream, scene->d64, make_camera<double>(*cam), F, eps);
-        else hipLaunchKernelGGL((trace_kernel<double, false>), grid, block, 0, stream, scene->d64, make_camera<double>(*cam), F, eps);
+        if (work_dev) hipLaunchKernelGGL((trace_kernel<double, true>), grid, block, 0, stream, scene->d64, make_camera<double>(*cam), F, eps, eps_rel);
+        else hipLaunchKernelGGL((trace_kernel<double, false>), grid, block, 0, stream, scene->d64, make_camera<double>(*cam), F, eps, eps_rel);
     } else {
-        if (work_dev) hipLaunchKernelGGL((trace_kernel<float, true>), grid, block, 0, stream, scene->d32, make_camera<float>(*cam), F, (float)eps);
-        else hipLaunchKernelGGL((trace_kernel<float, false>), grid, block, 0, stream, scene->d32, make_camera<float>(*cam), F, (float)eps);
+        if (work_dev) hipLaunchKernelGGL((trace_kernel<float, true>), grid, block, 0, stream, scene->d32, make_camera<float>(*cam), F, (float)eps, (float)eps_rel);
+        else hipLaunchKernelGGL((trace_kernel<float, false>), grid, block, 0, stream, scene->d32, make_camera<float>(*cam), F, (float)eps, (float)eps_rel);
     }
     HIP_TRY(hipGetLastError());
     return 0;
@@ -408,8 +409,8 @@ int launch(rtc_scene* scene, const rtc_camera* cam, const rtc_render_opts* opts,
 int render_host(rtc_scene* scene, const rtc_camera* cam, const rtc_render_opts* opts, int32_t n_tiles, const int32_t* tile_ids,
                 bool tiled, double* rgb_out, int32_t* hit_id_out, rtc_stats* stats_out) {
     int T, precision, depth;
-    double eps;
-    if (int rc = check_render_args(scene, cam, opts, &T, &precision, &depth, &eps)) return rc;
+    double eps, eps_rel;
+    if (int rc = check_render_args(scene, cam, opts, &T, &precision, &depth, &eps, &eps_rel)) return rc;
     if (!rgb_out) return fail(RTC_ERR_INVALID, "null rgb_out");
     if (tiled && (n_tiles < 0 || (n_tiles > 0 && !tile_ids))) return fail(RTC_ERR_INVALID, "bad tile list");
     int tiles_x = (cam->hsize + T - 1) / T, tiles_y = (cam->vsize + T - 1) / T;

@@ -244,13 +244,23 @@ template <class R> __device__ __forceinline__ int leaf_hits(const DScene<R>& S, 
     }
     const R* m = S.xform + 12 * (size_t)S.leaf_xform[leaf];
     Ray<R> r = {xpoint(m, ray.o), xvector(m, ray.d)};   // shapes.py:271-273, 1447-1448
-    switch (kind) {
-    case RTC_SPHERE: return sphere_hits(r, t);
-    case RTC_PLANE: return plane_hits(r, t);
-    case RTC_CUBE: return cube_hits(r, t);
-    case RTC_CYLINDER: return quadric_hits<R, false>(r, S.leaf_minmax[2 * leaf], S.leaf_minmax[2 * leaf + 1], S.leaf_closed[leaf] != 0, t);
-    default: return quadric_hits<R, true>(r, S.leaf_minmax[2 * leaf], S.leaf_minmax[2 * leaf + 1], S.leaf_closed[leaf] != 0, t);
+    if (kind == RTC_PLANE) return plane_hits(r, t);
+    if (kind == RTC_CUBE) return cube_hits(r, t);
+    // fp32 only: solve the quadratic from the point of the ray nearest the object's origin and add
+    // the shift back.  Same roots; it keeps b^2 - 4ac from cancelling when the eye is far from a
+    // small object (an fp64 solve does not need it and stays literal).
+    R shift = R(0);
+    if (sizeof(R) == 4) {
+        shift = -dot(r.o, r.d) / dot(r.d, r.d);
+        r.o = r.o + r.d * shift;
     }
+    int n;
+    if (kind == RTC_SPHERE) n = sphere_hits(r, t);
+    else if (kind == RTC_CYLINDER) n = quadric_hits<R, false>(r, S.leaf_minmax[2 * leaf], S.leaf_minmax[2 * leaf + 1], S.leaf_closed[leaf] != 0, t);
+    else n = quadric_hits<R, true>(r, S.leaf_minmax[2 * leaf], S.leaf_minmax[2 * leaf + 1], S.leaf_closed[leaf] != 0, t);
+    if (sizeof(R) == 4)
+        for (int k = 0; k < n; k++) t[k] += shift;
+    return n;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -702,7 +712,7 @@ __device__ __forceinline__ V3<R> light_surface(const DScene<R>& S, int material,
 
 // color_at for one primary ray, recursion unrolled into a stack of pending rays
 template <class R, class CNT>
-__device__ __forceinline__ V3<R> trace_pixel(const DScene<R>& S, Ray<R> primary, int max_depth, R shade_eps, int* stack,
+__device__ __forceinline__ V3<R> trace_pixel(const DScene<R>& S, Ray<R> primary, int max_depth, R shade_eps, R shade_eps_rel, int* stack,
                                              CNT& cnt, uint64_t seed, uint32_t pixel, int& hit_leaf_out) {
     Bounce<R> pending[RTC_MAX_BOUNCE_STACK];
     int np = 0;
@@ -726,8 +736,11 @@ __device__ __forceinline__ V3<R> trace_pixel(const DScene<R>& S, Ray<R> primary,
             V3<R> eyev = neg(ray.d);
             V3<R> reflectv = reflect(ray.d, normalv);
             if (dot(normalv, eyev) < R(0)) normalv = neg(normalv);
-            V3<R> over_point = point + normalv * shade_eps;
-            V3<R> under_point = point - normalv * shade_eps;
+            // fp32: the hit point carries the rounding of o + d*t, i.e. a few ulp of the larger of |o| and |p|
+            R scale = max_(max_(max_(abs_(point.x), abs_(point.y)), abs_(point.z)), max_(max_(abs_(ray.o.x), abs_(ray.o.y)), abs_(ray.o.z)));
+            R eps = max_(shade_eps, shade_eps_rel * scale);
+            V3<R> over_point = point + normalv * eps;
+            V3<R> under_point = point - normalv * eps;
             int material = S.leaf_material[leaf];
             const R* m = S.mat + 10 * (size_t)material;
             R reflective = m[7], transparency = m[8];

@@ -1,0 +1,87 @@
+"""Multi-GPU frame rendering: one process per GPU, image tiles sharded, one gather.
+
+The reference farms 2x2-pixel tiles to a process pool that writes a shared-memory canvas
+(renderer.py:781-835, canvas.py:60-61).  Here the unit is a 32x32 tile; tile i belongs to rank
+i mod N (interleaved, because sky and mesh pixels differ in cost by orders of magnitude); every
+rank holds the whole compiled scene; each traces its tiles into a compact [slot][ty][tx][c]
+buffer; ONE collective -- a gather to rank 0 (RCCL over xGMI with the `nccl` backend, `gloo`
+in CPU tests) -- and rank 0 un-permutes the tiles into the [x][y][c] canvas.  No rays or
+partial results cross GPUs, so there is nothing else to exchange.
+"""
+import numpy as np
+
+TILE = 32
+
+
+def tiles_for(hsize, vsize, tile=TILE):
+    return (hsize + tile - 1) // tile, (vsize + tile - 1) // tile
+
+
+def rank_tiles(hsize, vsize, world, rank, tile=TILE):
+    """Tile ids of `rank` (row-major tile numbering, interleaved over ranks)."""
+    tx, ty = tiles_for(hsize, vsize, tile)
+    return np.arange(tx * ty, dtype=np.int32)[rank::world]
+
+
+def slots_per_rank(hsize, vsize, world, tile=TILE):
+    tx, ty = tiles_for(hsize, vsize, tile)
+    return (tx * ty + world - 1) // world
+
+
+def unpermute_index(hsize, vsize, world, tile=TILE):
+    """(src, dst): flat pixel indices such that canvas.view(-1, 3)[dst] = gathered.view(-1, 3)[src],
+    where `gathered` is the concatenation over ranks of their (slots_per_rank, T, T, 3) buffers."""
+    tx, _ = tiles_for(hsize, vsize, tile)
+    per = slots_per_rank(hsize, vsize, world, tile)
+    slots = np.concatenate([np.pad(rank_tiles(hsize, vsize, world, r, tile),
+                                   (0, per - len(rank_tiles(hsize, vsize, world, r, tile))), constant_values=-1)
+                            for r in range(world)])
+    ly, lx = np.meshgrid(np.arange(tile), np.arange(tile), indexing="ij")
+    gx = (slots[:, None, None] % tx) * tile + lx[None]
+    gy = (slots[:, None, None] // tx) * tile + ly[None]
+    ok = (slots[:, None, None] >= 0) & (gx < hsize) & (gy < vsize)
+    return np.nonzero(ok.ravel())[0].astype(np.int64), (gx * vsize + gy)[ok].astype(np.int64)
+
+
+class FrameGather(object):
+    """Preallocated buffers + index tables for gathering one frame per call to rank 0."""
+
+    def __init__(self, hsize, vsize, world, rank, device, tile=TILE, group=None):
+        import torch
+        self.torch = torch
+        self.hsize, self.vsize, self.world, self.rank, self.tile, self.group = hsize, vsize, world, rank, tile, group
+        self.mine = rank_tiles(hsize, vsize, world, rank, tile)
+        per = slots_per_rank(hsize, vsize, world, tile)
+        self.compact = torch.zeros((per, tile, tile, 3), dtype=torch.float64, device=device)
+        self.tiles_dev = torch.from_numpy(self.mine.copy()).to(device)
+        self.frame = None
+        self.gathered = None
+        if rank == 0:
+            self.frame = torch.zeros((hsize, vsize, 3), dtype=torch.float64, device=device)
+            src, dst = unpermute_index(hsize, vsize, world, tile)
+            self.src, self.dst = torch.from_numpy(src).to(device), torch.from_numpy(dst).to(device)
+            if world > 1:
+                self.gathered = [torch.zeros_like(self.compact) for _ in range(world)]
+
+    def gather(self):
+        """After this rank's tiles are in `self.compact`: returns the canvas tensor on rank 0, None elsewhere."""
+        torch = self.torch
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.gather(self.compact, self.gathered, dst=0, group=self.group)
+            if self.rank != 0:
+                return None
+            flat = torch.cat([g.reshape(-1, 3) for g in self.gathered], dim=0)
+        else:
+            flat = self.compact.reshape(-1, 3)
+        self.frame.view(-1, 3).index_copy_(0, self.dst, flat.index_select(0, self.src))
+        return self.frame
+
+
+def render_distributed(scene, cam, fg, precision="fp64", max_depth=5, rays_ptr=None, stream=None, count_work=False):
+    """One frame: trace this rank's tiles with the HIP kernel into fg.compact, then gather.
+    `scene` is an `_ffi.Scene` on this rank's GPU; `fg` a FrameGather built for `cam`'s size."""
+    scene.render_device(cam, fg.compact.data_ptr(), rays_ptr=rays_ptr, tile_ids_ptr=fg.tiles_dev.data_ptr(),
+                        n_tiles=len(fg.mine), precision=precision, max_depth=max_depth, tile_size=fg.tile,
+                        stream=stream, count_work=count_work)
+    return fg.gather()

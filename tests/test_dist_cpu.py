@@ -1,0 +1,61 @@
+"""The multi-GPU path's host logic with world_size 2 on the CPU (gloo): tile partition, the one
+gather, the un-permute.  Each rank's tiles are filled by the CPU oracle in place of the HIP
+kernel (this is a test: the product path never does that), so the assembled frame can be
+compared with a whole-frame render."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT, load_pack
+from ray_tracer_challenge_amd.dist import FrameGather, rank_tiles, slots_per_rank, tiles_for, unpermute_index
+
+
+def test_partition_covers_every_tile_once():
+    for (w, h, n) in [(100, 100, 2), (1920, 1080, 8), (33, 65, 3), (8, 8, 4)]:
+        tx, ty = tiles_for(w, h)
+        got = np.sort(np.concatenate([rank_tiles(w, h, n, r) for r in range(n)]))
+        assert np.array_equal(got, np.arange(tx * ty))
+        src, dst = unpermute_index(w, h, n)
+        assert len(dst) == w * h and len(np.unique(dst)) == w * h
+        assert src.max() < n * slots_per_rank(w, h, n) * 32 * 32
+
+
+def _worker(rank, world, port, out_path):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle.oracle import Oracle
+        cam, scene_world, _ = load_pack("cover", (72, 40))
+        fg = FrameGather(cam.hsize, cam.vsize, world, rank, torch.device("cpu"))
+        tx, _ = tiles_for(cam.hsize, cam.vsize)
+        T = fg.tile
+        o = Oracle(scene_world)
+        buf = fg.compact.numpy()
+        for k, tile in enumerate(fg.mine):          # what rtc_render_device writes: [slot][ty][tx][c]
+            x0, y0 = (tile % tx) * T, (tile // tx) * T
+            xs, ys = np.meshgrid(np.arange(x0, min(x0 + T, cam.hsize)), np.arange(y0, min(y0 + T, cam.vsize)), indexing="xy")
+            rgb, _, _, _ = o.render_pixels(cam, xs.ravel(), ys.ravel(), threads=2)
+            buf[k, :xs.shape[0], :xs.shape[1]] = rgb.reshape(xs.shape[0], xs.shape[1], 3)
+        frame = fg.gather()
+        assert (frame is None) == (rank != 0)
+        if rank == 0:
+            np.save(out_path, frame.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gather_reassembles_the_frame(tmp_path, oracle_cls):
+    out = str(tmp_path / "frame.npy")
+    port = 29000 + os.getpid() % 2000
+    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    got = np.load(out)
+    cam, world, _ = load_pack("cover", (72, 40))
+    want, _, _ = oracle_cls(world).render(cam)
+    np.testing.assert_array_equal(got, want)

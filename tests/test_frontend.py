@@ -1,0 +1,251 @@
+"""Host logic: YAML define/extend macros, OBJ parsing, Group.divide, scene packs, the compiler's
+output, PPM quantisation.  Where /root/reference is present (build container only) the loaders
+are also cross-checked against the reference's own on its shipped scenes."""
+import io
+import os
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, load_pack
+from ray_tracer_challenge_amd import shapes as S
+from ray_tracer_challenge_amd.canvas import Canvas, color, construct_ppm, quantize
+from ray_tracer_challenge_amd.compile import compile_scene, K_CSG_ROOT, K_PLANE
+from ray_tracer_challenge_amd.matrix import Transform, rotation_x, scaling, translation
+from ray_tracer_challenge_amd.obj_parser import OBJParser, obj_to_group
+from ray_tracer_challenge_amd.renderer import World
+from ray_tracer_challenge_amd.scene_io import load_world, save_scene
+from ray_tracer_challenge_amd.vector import point
+from ray_tracer_challenge_amd.yaml_parser import yaml_text_to_world_objects
+
+YAML = """
+- add: camera
+  width: 40
+  height: 20
+  field-of-view: 0.7
+  from: [0, 1, -5]
+  to: [0, 0, 0]
+  up: [0, 1, 0]
+- add: light
+  at: [-10, 10, -10]
+  intensity: [1, 1, 1]
+- add: config
+  thread-count: 2
+  divide-threshold: 3
+- define: base-material
+  value:
+    color: [1, 0, 0]
+    diffuse: 0.5
+- define: shiny
+  extend: base-material
+  value:
+    reflective: 0.25
+- define: std
+  value:
+  - [ translate, 1, 0, 0 ]
+  - [ scale, 2, 2, 2 ]
+- define: big
+  value:
+  - std
+  - [ scale, 3, 3, 3 ]
+- define: leg
+  value:
+    add: group
+    transform:
+    - [ rotate-y, 0.5 ]
+    children:
+    - add: sphere
+    - add: cylinder
+      min: 0
+      max: 1
+- add: sphere
+  material: shiny
+  transform:
+  - big
+  - [ translate, 0, 1, 0 ]
+- add: cube
+  material:
+    color: [0, 1, 0]
+    shadow: false
+- add: leg
+  material:
+    color: [0, 0, 1]
+  transform:
+  - [ translate, 0, 0, 2 ]
+- add: csg
+  op: difference
+  left:
+    add: cube
+  right:
+    add: sphere
+    transform:
+    - [ translate, 0.5, 0.5, 0 ]
+"""
+
+
+def test_yaml_define_extend_and_instancing():
+    objs = yaml_text_to_world_objects(YAML)
+    assert objs["camera"].hsize == 40 and objs["config"].thread_count == 2 and objs["config"].divide_threshold == 3
+    root = objs["world"][0]
+    assert type(root).__name__ == "Group" and len(root.children) == 4
+    sph, cube, leg, csg = root.children
+    # extend: parent copied, child keys overlaid (yaml_parser.py:36-45)
+    assert np.allclose(sph.material.color, [1, 0, 0]) and sph.material.diffuse == 0.5 and sph.material.reflective == 0.25
+    # nested transform defines are spliced in order; list applies first-to-last (matrix.py:128-132)
+    want = translation(0, 1, 0).arr @ scaling(3, 3, 3).arr @ scaling(2, 2, 2).arr @ translation(1, 0, 0).arr
+    assert np.allclose(sph.transform.arr, want)
+    assert cube.material.casts_shadow is False
+    # add: <define>: the define's transform entries go first; group material flows to children (shapes.py:249-254)
+    assert np.allclose(leg.transform.arr, translation(0, 0, 2).arr @ Transform.from_yaml([["rotate-y", 0.5]]).arr)
+    assert all(np.allclose(c.material.color, [0, 0, 1]) for c in leg.children)
+    assert leg.children[1].closed is True           # YAML cylinders default to closed (shapes.py:725-727)
+    assert csg.op is S.CSGDifference and csg.left.parent is csg
+
+
+def test_obj_parser_fan_and_groups():
+    text = """
+v -1 1 0
+v -1.0000 0.0000 0.0000
+v 1 0 0
+v 1 1 0
+v 0 2 0
+vn 0 0 1
+vn 0 0 1
+vn 0 0 1
+
+g First
+f 1//1 2//2 3//3 4//1 5//2
+g Second
+f 1/9/1 3/9/2 4/9/3
+g Empty
+"""
+    p = OBJParser(io.StringIO(text))
+    assert len(p.vertices) == 6 and len(p.normals) == 4
+    g = obj_to_group(p)
+    names = [len(c.children) for c in g.children]
+    assert names == [3, 1]                           # fan of a pentagon = 3 triangles; empty groups dropped
+    t = g.children[0].children[1]
+    assert type(t).__name__ == "SmoothTriangle"
+    assert t.p1.compare(point(-1, 1, 0)) and t.p2.compare(point(1, 0, 0)) and t.p3.compare(point(1, 1, 0))
+    with pytest.raises(ValueError):
+        OBJParser(io.StringIO("v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 3\n"))   # the reference fails on normal-less faces too
+
+
+def test_divide_partitions_like_the_reference():
+    # three spheres left, one right, one straddling the split plane (shapes.py:480-507)
+    g = S.group()
+    xs = [-4, -3.5, -3, 4, 0]
+    kids = []
+    for x in xs:
+        s = S.sphere()
+        s.transform = translation(x, 0, 0)
+        kids.append(s)
+    g.add_child(kids)
+    g.divide(1)
+    # children's LOCAL bounds (unit cubes at the origin) straddle every split: nothing moves (shapes.py:502)
+    assert len(g.children) == 5
+    tris = [S.triangle(point(x, 0, 0), point(x + 0.5, 0, 0), point(x, 0.5, 0)) for x in (-4, -3, 3, 4)]
+    g = S.group()
+    g.add_child(tris)
+    g.divide(1)
+    assert [type(c).__name__ for c in g.children] == ["Group", "Group"]
+    assert sorted(len(c.children) for c in g.children) == [2, 2]     # each half was split again into 1 + 1 sub-groups
+    leaves = compile_scene(World([], [g])).counts["n_leaves"]
+    assert leaves == 4
+
+
+def test_divide_copies_parent_transform_quirk():
+    g = S.Group(S.Material(), translation(0, 5, 0), [])
+    tris = [S.triangle(point(x, 0, 0), point(x + 0.5, 0, 0), point(x, 0.5, 0)) for x in (-4, -3, 3, 4)]
+    g.add_child(tris)
+    before = compile_scene(World([], [g])).arrays["tri_geom"][:, 1].copy()
+    g.divide(1)
+    after = compile_scene(World([], [g])).arrays["tri_geom"][:, 1]
+    # sub-groups carry a copy of the parent's transform (shapes.py:492): y moves by another +5 per level
+    assert np.allclose(before, 5) and np.all(after >= 10)
+
+
+def test_scene_pack_roundtrip(tmp_path):
+    objs = yaml_text_to_world_objects(YAML)
+    w = World(objs["lights"], objs["world"])
+    a = compile_scene(w)
+    path = str(tmp_path / "scene.npz")
+    save_scene(path, objs["camera"], w, objs["config"], {"k": 1})
+    cam, w2, o2 = load_world(path)
+    b = compile_scene(w2)
+    assert o2["meta"] == {"k": 1} and o2["config"].divide_threshold == 3 and cam.hsize == 40
+    assert a.counts == b.counts
+    for k in a.arrays:
+        np.testing.assert_array_equal(a.arrays[k], b.arrays[k], err_msg=k)
+
+
+def test_compiled_scene_structure():
+    objs = yaml_text_to_world_objects(YAML)
+    cs = compile_scene(World(objs["lights"], objs["world"]))
+    A, C = cs.arrays, cs.counts
+    assert C["n_leaves"] == 6 and C["n_csg_roots"] == 1 and C["n_csg_nodes"] == 1 and C["n_unbounded"] == 0
+    assert list(A["csg_root"][0]) == [0, 1, 4, 6] and list(A["csg_node"][0][:4]) == [2, 4, 5, 6]
+    kinds = (A["item_prim"].view(np.uint32) >> 28).tolist()
+    assert kinds.count(K_CSG_ROOT) == 1 and len(kinds) == 5
+    noshadow = ((A["item_prim"].view(np.uint32) >> 27) & 1).tolist()
+    assert sum(noshadow) == 1                                        # the `shadow: false` cube
+    assert np.all(A["item_lo"] <= A["item_hi"])
+    cam, world, _ = load_pack("cover")
+    cs = compile_scene(world)
+    assert cs.counts["n_unbounded"] == 1 and (cs.arrays["unbounded_prim"].view(np.uint32)[0] >> 28) == K_PLANE
+
+
+def test_triangles_move_to_world_space():
+    t = S.triangle(point(0, 1, 0), point(-1, 0, 0), point(1, 0, 0))
+    g = S.Group(S.Material(), scaling(2, 2, 2), [t])
+    outer = S.Group(S.Material(), translation(0, 0, 5), [g])
+    cs = compile_scene(World([], [outer]))
+    geom = cs.arrays["tri_geom"][0]
+    assert np.allclose(geom[0:3], [0, 2, 5]) and np.allclose(geom[3:6], [-2, -2, 0]) and np.allclose(geom[6:9], [2, -2, 0])
+    assert np.isclose(geom[9], 1e-6 * 8)                             # EPSILON * |det(object->world)|
+    n = cs.arrays["tri_norm"][0][:3]
+    assert np.allclose(n / np.linalg.norm(n), [0, 0, -1])
+
+
+def test_pattern_programs():
+    W, B = color(1, 1, 1), color(0, 0, 0)
+    s = S.sphere()
+    s.material.pattern = S.NestedPattern(S.Checkers(W, B), S.Stripe(W, B), S.BlendedPattern(S.Ring(W, B), S.Gradient(W, B)))
+    cs = compile_scene(World([], [s]))
+    ops = cs.arrays["instr"][:cs.counts["n_instr"], 0].tolist()
+    assert ops == [0, 0, 0, 2, 1]                                    # stripe, ring, gradient, BLEND, EVAL_AB(checkers)
+    s.material.pattern = S.PerturbedPattern(S.Stripe(W, B))
+    with pytest.raises(NotImplementedError):
+        compile_scene(World([], [s]))
+
+
+def test_quantize_rule():
+    ca = Canvas(2, 1)
+    ca[0, 0] = color(1.5, 0.5, -0.2)
+    ca[1, 0] = color(0.999, 0.001, 1.0)
+    assert quantize(ca, True).tolist() == [[[255, 128, 0], [255, 0, 255]]]
+    assert quantize(ca, False)[0, 0].tolist() == [255, 85, 0]       # scaled by the canvas maximum 1.5
+    assert construct_ppm(ca).startswith(b"P6\n2 1\n255\n")
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="reference not present (GPU box)")
+@pytest.mark.parametrize("rel,cwd", [("cover/cover.yml", ""), ("csg_test.yml", ""), ("group_test/group.yml", ""),
+                                     ("shadow_glamour_shot/shadow_glamour_shot.yml", ""),
+                                     ("obj_file_test/obj_file_test.yml", "objects")])
+def test_loader_matches_reference_loader(rel, cwd):
+    """Same YAML through the reference's loader and ours -> identical compiled scenes (up to leaf order)."""
+    from oracle import ref_harness as rh
+    from oracle.make_golden import leaf_keys
+    from ray_tracer_challenge_amd.yaml_parser import yaml_file_to_world_objects
+    path = os.path.join(rh.REF, rel)
+    with rh.chdir(os.path.join(rh.REF, cwd)):
+        mine = yaml_file_to_world_objects(path)
+    mods, objs, w = rh.load_reference_scene(path, cwd=os.path.join(rh.REF, cwd))
+    a = compile_scene(World(mine["lights"], mine["world"]))
+    b = compile_scene(w)
+    assert a.counts == b.counts
+    assert sorted(leaf_keys(a)) == sorted(leaf_keys(b))
+    np.testing.assert_array_equal(a.arrays["light_geom"], b.arrays["light_geom"])
+    ma = sorted(map(tuple, a.arrays["mat"][a.arrays["leaf_material"][:a.counts["n_leaves"]]].tolist()))
+    mb = sorted(map(tuple, b.arrays["mat"][b.arrays["leaf_material"][:b.counts["n_leaves"]]].tolist()))
+    assert ma == mb
