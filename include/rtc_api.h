@@ -135,6 +135,10 @@ typedef struct {
 /* Run the instrumented kernel variant that also counts work items (slower; for roofline
  * accounting, never for timing). */
 #define RTC_FLAG_COUNT_WORK 1
+/* Use the wavefront pipeline (rays in HBM queues, one sweep of small kernels per bounce level)
+ * instead of the default single kernel (one lane = one pixel, in-lane bounce stack).  Same
+ * results to rounding; slower on every scene measured so far, kept for A/B measurements. */
+#define RTC_FLAG_WAVEFRONT 2
 
 typedef struct {
     int32_t precision;   /* 64 = fp64 (reference arithmetic), 32 = fp32 throughput mode */

@@ -5,13 +5,16 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
 #include "../../include/rtc_api.h"
 #include "rtc_bvh.hpp"
 #include "rtc_device.hpp"
+#include "rtc_wavefront.hpp"
 
 namespace {
 
@@ -36,16 +39,15 @@ int fail(int code, const char* fmt, ...) {
 // ---------------------------------------------------------------------------------------------
 // kernels
 // ---------------------------------------------------------------------------------------------
-template <class R, bool PROF>
-__global__ __launch_bounds__(RTC_BLOCK) void trace_kernel(rtc::DScene<R> S, rtc::DCamera<R> cam, rtc::DFrame F, R shade_eps, R shade_eps_rel) {
+template <class R, bool PROF, bool CSG>
+__global__ __launch_bounds__(RTC_BLOCK, (sizeof(R) == 8 ? RTC_WAVES_F64 : RTC_WAVES_F32)) void trace_kernel(rtc::DScene<R> S, rtc::DCamera<R> cam, rtc::DFrame F, R shade_eps, R shade_eps_rel) {
     __shared__ int s_stack[RTC_BVH_STACK * RTC_BLOCK];
     int* stack = s_stack + threadIdx.x;
     const int T = F.tile_size, per_tile = T * T, sub = T / 8;
     long long w = (long long)blockIdx.x * RTC_BLOCK + threadIdx.x;
     int slot = (int)(w / per_tile), within = (int)(w % per_tile);
-    rtc::Counters<PROF> cnt;
-    for (int k = 0; k < 4; k++) cnt.c[k] = 0;
-    for (int k = 0; k < (PROF ? rtc::W_COUNT : 1); k++) cnt.w[k] = 0;
+    rtc::Counters<PROF, CSG> cnt;
+    rtc::zero_counters(cnt);
     if (slot < F.n_tiles) {
         int tile = F.tile_ids ? F.tile_ids[slot] : slot;
         int tx0 = (tile % F.tiles_x) * T, ty0 = (tile / F.tiles_x) * T;
@@ -68,28 +70,7 @@ __global__ __launch_bounds__(RTC_BLOCK) void trace_kernel(rtc::DScene<R> S, rtc:
             if (F.hit_id) F.hit_id[o] = hit_leaf;
         }
     }
-    if (F.rays) {   // block-level reduction of the ray counters, then 4 atomics per block
-        __syncthreads();
-        unsigned int* red = reinterpret_cast<unsigned int*>(s_stack);
-        for (int k = 0; k < 4; k++) {
-            unsigned int v = cnt.c[k];
-            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-            if ((threadIdx.x & 63) == 0) red[k * (RTC_BLOCK / 64) + (threadIdx.x >> 6)] = v;
-        }
-        __syncthreads();
-        if (threadIdx.x < 4) {
-            unsigned long long s = 0;
-            for (int q = 0; q < RTC_BLOCK / 64; q++) s += red[threadIdx.x * (RTC_BLOCK / 64) + q];
-            if (s) atomicAdd(F.rays + threadIdx.x, s);
-        }
-    }
-    if (PROF && F.work) {
-        for (int k = 0; k < rtc::W_COUNT; k++) {
-            unsigned int v = cnt.w[k];
-            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-            if ((threadIdx.x & 63) == 0 && v) atomicAdd(F.work + k, (unsigned long long)v);
-        }
-    }
+    rtc::flush_counters(cnt, F, reinterpret_cast<unsigned int*>(s_stack));
 }
 
 // canvas.py:133-156
@@ -168,7 +149,16 @@ struct rtc_scene {
     DeviceArena mem64, mem32, shared;
     rtc::DScene<double> d64;
     rtc::DScene<float> d32;
-    bool has_jitter = false;
+    bool has_jitter = false, has_csg = false;
+    // wavefront ray pools, one per precision, grown on demand and reused across frames
+    std::mutex ws_mutex;
+    DeviceArena ws_mem64, ws_mem32;
+    rtc::WfSpace<double> ws64{};
+    rtc::WfSpace<float> ws32{};
+    int ws_lights64 = 0, ws_lights32 = 0;
+    double ws_factor = 6.0;   // pool capacity in rays per level-0 work item
+    int last_overflow = 0;
+    int mask_words = 1;       // 32-bit words of shadow bits per (ray, light): ceil(max light samples / 32)
 };
 
 namespace {
@@ -194,8 +184,8 @@ int upload_real(const rtc_scene_desc& d, const std::vector<double>& node_box, De
     UP_REAL(light_geom, d.light_geom, 9 * (size_t)d.n_lights);
     UP_REAL(light_intensity, d.light_intensity, 3 * (size_t)d.n_lights);
 #undef UP_REAL
-    std::vector<R> nb = pad_boxes<R>(node_box);
-    return A.upload(nb.data(), nb.size(), &S.node_box);
+    (void)node_box;
+    return 0;
 }
 
 int validate(const rtc_scene_desc& d) {
@@ -289,15 +279,34 @@ int validate(const rtc_scene_desc& d) {
 }
 
 int create_impl(const rtc_scene_desc& d, rtc_scene* sc) {
-    // ---- BVH over the bounded items (host) ----
-    std::vector<rtc::Aabb> boxes((size_t)d.n_items);
-    for (int i = 0; i < d.n_items; i++)
-        for (int k = 0; k < 3; k++) { boxes[i].lo[k] = d.item_lo[3 * i + k]; boxes[i].hi[k] = d.item_hi[3 * i + k]; }
-    rtc::Bvh bvh = rtc::build_bvh(boxes, 4, RTC_BVH_STACK - 2);
-    if (bvh.depth > RTC_BVH_STACK - 1) return fail(RTC_ERR_LIMIT, "BVH depth %d exceeds traversal stack", bvh.depth);
-    sc->bvh_nodes = bvh.n_nodes(); sc->bvh_depth = bvh.depth; sc->bvh_max_leaf = bvh.max_leaf;
-    std::vector<int32_t> prims((size_t)d.n_items);
-    for (int i = 0; i < d.n_items; i++) prims[i] = d.item_prim[bvh.order[i]];
+    // ---- two BVHs over the bounded items (host): analytic leaves + CSG roots, and triangles ----
+    std::vector<rtc::Aabb> obox, tbox;
+    std::vector<int32_t> oprim, tprim;
+    for (int i = 0; i < d.n_items; i++) {
+        rtc::Aabb b;
+        for (int k = 0; k < 3; k++) { b.lo[k] = d.item_lo[3 * i + k]; b.hi[k] = d.item_hi[3 * i + k]; }
+        bool is_tri = ((uint32_t)d.item_prim[i] >> 28) == RTC_TRIANGLE;
+        (is_tri ? tbox : obox).push_back(b);
+        (is_tri ? tprim : oprim).push_back(d.item_prim[i]);
+    }
+    int tri_leaf = 2;                                   // triangles per BVH leaf (development override: RTC_BVH_LEAF)
+    if (const char* e = getenv("RTC_BVH_LEAF")) { int v = atoi(e); if (v >= 1 && v <= 16) tri_leaf = v; }
+    rtc::Bvh bvh = rtc::build_bvh(obox, 4, RTC_BVH_STACK - 2);
+    rtc::Bvh tbvh = rtc::build_bvh(tbox, tri_leaf, RTC_BVH_STACK - 2);
+    if (bvh.depth > RTC_BVH_STACK - 1 || tbvh.depth > RTC_BVH_STACK - 1) return fail(RTC_ERR_LIMIT, "BVH depth exceeds traversal stack");
+    sc->bvh_nodes = bvh.n_nodes() + tbvh.n_nodes(); sc->bvh_depth = std::max(bvh.depth, tbvh.depth);
+    sc->bvh_max_leaf = std::max(bvh.max_leaf, tbvh.max_leaf);
+    std::vector<int32_t> prims(oprim.size());
+    for (size_t i = 0; i < oprim.size(); i++) prims[i] = oprim[bvh.order[i]];
+    // triangles in BVH leaf order: geometry rows + (leaf id | noshadow << 31)
+    std::vector<double> tb_geom(12 * tprim.size());
+    std::vector<int32_t> tb_leaf(tprim.size());
+    for (size_t i = 0; i < tprim.size(); i++) {
+        uint32_t code = (uint32_t)tprim[tbvh.order[i]];
+        uint32_t row = code & 0x07FFFFFFu;
+        memcpy(&tb_geom[12 * i], d.tri_geom + 12 * (size_t)row, 12 * sizeof(double));
+        tb_leaf[i] = (int32_t)((uint32_t)d.tri_leaf[row] | (((code >> 27) & 1u) << 31));
+    }
 
     // ---- precision-independent arrays (uploaded once, shared by both DScene views) ----
     rtc::DScene<double>& S = sc->d64;
@@ -311,8 +320,8 @@ int create_impl(const rtc_scene_desc& d, rtc_scene* sc) {
     UP(leaf_tri, d.leaf_tri, d.n_leaves);
     UP(leaf_closed, d.leaf_closed, d.n_leaves);
     UP(tri_leaf, d.tri_leaf, d.n_tris);
-    UP(node_child, bvh.child.data(), bvh.child.size());
     UP(bvh_prims, prims.data(), prims.size());
+    UP(tb_leaf, tb_leaf.data(), tb_leaf.size());
     UP(unbounded_prims, d.unbounded_prim, d.n_unbounded);
     UP(csg_root, d.csg_root, 4 * (size_t)d.n_csg_roots);
     UP(csg_node, d.csg_node, 5 * (size_t)d.n_csg_nodes);
@@ -333,19 +342,43 @@ int create_impl(const rtc_scene_desc& d, rtc_scene* sc) {
 #undef UP
     S.n_leaves = d.n_leaves;
     S.n_bvh_nodes = bvh.n_nodes();
+    S.n_tnodes = tbvh.n_nodes();
     S.n_unbounded = d.n_unbounded;
     S.n_lights = d.n_lights;
 
     rtc::DScene<float>& F = sc->d32;
 #define CP(field) F.field = S.field
     CP(n_leaves); CP(leaf_kind); CP(leaf_xform); CP(leaf_material); CP(leaf_tri); CP(leaf_closed); CP(tri_leaf);
-    CP(n_bvh_nodes); CP(node_child); CP(bvh_prims); CP(n_unbounded); CP(unbounded_prims); CP(csg_root); CP(csg_node);
+    CP(n_bvh_nodes); CP(bvh_prims); CP(n_tnodes); CP(tb_leaf); CP(n_unbounded); CP(unbounded_prims); CP(csg_root); CP(csg_node);
     CP(mat_shadow); CP(mat_program); CP(pat_type); CP(pat_child); CP(pat_tex); CP(prog_off); CP(prog_len); CP(instr);
     CP(tex_off); CP(tex_w); CP(tex_h); CP(tex_data); CP(n_lights); CP(light_type); CP(light_steps);
 #undef CP
+    {
+        auto pack = [](const rtc::Bvh& b) {
+            std::vector<float> boxes = pad_boxes<float>(b.box);
+            std::vector<rtc::BvhNode> out((size_t)b.n_nodes());
+            for (int i = 0; i < b.n_nodes(); i++) {
+                memcpy(out[i].box, &boxes[12 * (size_t)i], 12 * sizeof(float));
+                out[i].child[0] = b.child[2 * (size_t)i]; out[i].child[1] = b.child[2 * (size_t)i + 1];
+                out[i].pad[0] = out[i].pad[1] = 0;
+            }
+            return out;
+        };
+        std::vector<rtc::BvhNode> on = pack(bvh), tn = pack(tbvh);
+        if (int rc = A.upload(on.data(), on.size(), &S.nodes)) return rc;
+        if (int rc = A.upload(tn.data(), tn.size(), &S.tnodes)) return rc;
+        F.nodes = S.nodes; F.tnodes = S.tnodes;
+        if (int rc = sc->mem64.upload(tb_geom.data(), tb_geom.size(), &sc->d64.tb_geom)) return rc;
+        std::vector<float> g32 = cast_vec<float>(tb_geom.data(), tb_geom.size());
+        if (int rc = sc->mem32.upload(g32.data(), g32.size(), &sc->d32.tb_geom)) return rc;
+    }
     if (int rc = upload_real<double>(d, bvh.box, sc->mem64, sc->d64)) return rc;
     if (int rc = upload_real<float>(d, bvh.box, sc->mem32, sc->d32)) return rc;
-    for (int i = 0; i < d.n_lights; i++) if (d.light_type[i] == 1 && d.light_steps[3 * i + 2]) sc->has_jitter = true;
+    sc->has_csg = d.n_csg_roots > 0;
+    for (int i = 0; i < d.n_lights; i++) {
+        if (d.light_type[i] == 1 && d.light_steps[3 * i + 2]) sc->has_jitter = true;
+        if (d.light_type[i] == 1) sc->mask_words = std::max(sc->mask_words, (d.light_steps[3 * i] * d.light_steps[3 * i + 1] + 31) / 32);
+    }
     return 0;
 }
 
@@ -374,6 +407,68 @@ int check_render_args(const rtc_scene* scene, const rtc_camera* cam, const rtc_r
     return 0;
 }
 
+__global__ void wf_init(rtc::WfCtrl* ctrl, int n0) {
+    for (int k = 0; k < RTC_WF_MAX_LEVELS; k++) ctrl->count[k] = 0;
+    ctrl->count[0] = n0;
+    ctrl->overflow = 0;
+}
+
+template <class R>
+int ensure_workspace(rtc::WfSpace<R>& W, DeviceArena& A, int& have_lights, long long cap, int n_lights, int mask_words) {
+    if (W.ray && W.cap >= cap && have_lights >= n_lights * mask_words) { W.mask_words = mask_words; return 0; }
+    A.release();
+    A.bytes = 0;
+    memset(&W, 0, sizeof(W));
+    size_t n = (size_t)cap, nl = (size_t)std::max(1, n_lights * mask_words);
+#define WS_ALLOC(field, type, count) do { void* p_ = nullptr; size_t sz_ = (count) * sizeof(type); HIP_TRY(hipMalloc(&p_, sz_)); A.ptrs.push_back(p_); A.bytes += sz_; W.field = static_cast<type*>(p_); } while (0)
+    WS_ALLOC(ray, rtc::WfRay<R>, n);
+    WS_ALLOC(hit, rtc::WfHit<R>, n);
+    WS_ALLOC(pix, int32_t, n);
+    WS_ALLOC(link, rtc::WfLink<R>, n);
+    WS_ALLOC(col, rtc::WfCol<R>, n);
+    WS_ALLOC(cst, rtc::WfCst<R>, n);
+    WS_ALLOC(opt, rtc::WfPt<R>, n);
+    WS_ALLOC(mask, uint32_t, n * nl);
+    WS_ALLOC(ctrl, rtc::WfCtrl, 1);
+#undef WS_ALLOC
+    W.cap = (int32_t)cap;
+    W.mask_words = mask_words;
+    have_lights = (int)nl;
+    return 0;
+}
+
+template <class R, bool PROF>
+int run_wavefront(const rtc::DScene<R>& S, const rtc::DCamera<R>& cam, rtc::WfSpace<R>& W, const rtc::DFrame& F, R eps, R eps_rel,
+                  long long n0, hipStream_t stream) {
+    rtc::WfParams<R> P;
+    P.W = W; P.F = F; P.shade_eps = eps; P.shade_eps_rel = eps_rel; P.level = 0;
+    const int D = F.max_depth;
+    const unsigned fixed = 2048;                       // grid-stride grid for levels whose size only the GPU knows
+    dim3 block(RTC_BLOCK);
+    hipLaunchKernelGGL(wf_init, dim3(1), dim3(1), 0, stream, W.ctrl, (int)n0);
+    for (int L = 0; L <= D; L++) {
+        P.level = L;
+        unsigned g_rays = L == 0 ? (unsigned)((n0 + RTC_BLOCK - 1) / RTC_BLOCK) : fixed;
+        long long shadow_items = n0 * (S.n_lights + 1);
+        unsigned g_shadow = L == 0 ? (unsigned)std::min<long long>((shadow_items + RTC_BLOCK - 1) / RTC_BLOCK, 1 << 20) : fixed;
+        if (L > 0) hipLaunchKernelGGL(rtc::wf_clamp, dim3(1), dim3(1), 0, stream, W.ctrl, L, W.cap);
+        hipLaunchKernelGGL((rtc::wf_trace<R, PROF>), dim3(g_rays), block, 0, stream, S, cam, P);
+        if (S.n_tnodes > 0) hipLaunchKernelGGL((rtc::wf_trace_tri<R, PROF>), dim3(g_rays), block, 0, stream, S, P);
+        hipLaunchKernelGGL((rtc::wf_shadow<R, PROF>), dim3(g_shadow), block, 0, stream, S, P);
+        if (S.n_tnodes > 0) hipLaunchKernelGGL((rtc::wf_shadow_tri<R, PROF>), dim3(g_shadow), block, 0, stream, S, P);
+        hipLaunchKernelGGL((rtc::wf_shade<R, PROF>), dim3(g_rays), block, 0, stream, S, P);
+    }
+    for (int L = D - 1; L >= 0; L--) {
+        P.level = L;
+        unsigned g = L == 0 ? (unsigned)((n0 + RTC_BLOCK - 1) / RTC_BLOCK) : fixed;
+        hipLaunchKernelGGL((rtc::wf_reduce<R>), dim3(g), block, 0, stream, P);
+    }
+    P.level = 0;
+    hipLaunchKernelGGL((rtc::wf_output<R>), dim3((unsigned)((n0 + RTC_BLOCK - 1) / RTC_BLOCK)), block, 0, stream, P, cam.hsize, cam.vsize);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 int launch(rtc_scene* scene, const rtc_camera* cam, const rtc_render_opts* opts, int32_t n_tiles, const int32_t* tile_ids_dev,
            double* rgb_dev, int32_t* hit_id_dev, int64_t* rays_dev, int64_t* work_dev, hipStream_t stream) {
     int T, precision, depth;
@@ -393,14 +488,33 @@ int launch(rtc_scene* scene, const rtc_camera* cam, const rtc_render_opts* opts,
     long long blocks = (work + RTC_BLOCK - 1) / RTC_BLOCK;
     if (blocks > 0x7FFFFFFFLL) return fail(RTC_ERR_LIMIT, "too many blocks");
     F.work = reinterpret_cast<unsigned long long*>(work_dev);
-    dim3 grid((unsigned)blocks), block(RTC_BLOCK);
-    if (precision == 64) {
-        if (work_dev) hipLaunchKernelGGL((trace_kernel<double, true>), grid, block, 0, stream, scene->d64, make_camera<double>(*cam), F, eps, eps_rel);
-        else hipLaunchKernelGGL((trace_kernel<double, false>), grid, block, 0, stream, scene->d64, make_camera<double>(*cam), F, eps, eps_rel);
-    } else {
-        if (work_dev) hipLaunchKernelGGL((trace_kernel<float, true>), grid, block, 0, stream, scene->d32, make_camera<float>(*cam), F, (float)eps, (float)eps_rel);
-        else hipLaunchKernelGGL((trace_kernel<float, false>), grid, block, 0, stream, scene->d32, make_camera<float>(*cam), F, (float)eps, (float)eps_rel);
+    const bool wavefront = opts && (opts->flags & RTC_FLAG_WAVEFRONT);
+    if (wavefront) {
+        std::lock_guard<std::mutex> lock(scene->ws_mutex);
+        long long cap = (long long)(work * scene->ws_factor) + 4096;
+        if (cap > 0x7FFFFF00LL) cap = 0x7FFFFF00LL;
+        if (cap < work) return fail(RTC_ERR_LIMIT, "frame too large for the wavefront ray pool");
+        if (precision == 64) {
+            if (int rc = ensure_workspace(scene->ws64, scene->ws_mem64, scene->ws_lights64, cap, scene->d64.n_lights, scene->mask_words)) return rc;
+            if (work_dev) return run_wavefront<double, true>(scene->d64, make_camera<double>(*cam), scene->ws64, F, eps, eps_rel, work, stream);
+            return run_wavefront<double, false>(scene->d64, make_camera<double>(*cam), scene->ws64, F, eps, eps_rel, work, stream);
+        }
+        if (int rc = ensure_workspace(scene->ws32, scene->ws_mem32, scene->ws_lights32, cap, scene->d32.n_lights, scene->mask_words)) return rc;
+        if (work_dev) return run_wavefront<float, true>(scene->d32, make_camera<float>(*cam), scene->ws32, F, (float)eps, (float)eps_rel, work, stream);
+        return run_wavefront<float, false>(scene->d32, make_camera<float>(*cam), scene->ws32, F, (float)eps, (float)eps_rel, work, stream);
     }
+    dim3 grid((unsigned)blocks), block(RTC_BLOCK);
+    const bool csg = scene->has_csg;
+#define RTC_LAUNCH_MEGA(R, PROF, CSG, SC, EPS, EPSREL) \
+    hipLaunchKernelGGL((trace_kernel<R, PROF, CSG>), grid, block, 0, stream, SC, make_camera<R>(*cam), F, (R)(EPS), (R)(EPSREL))
+    if (precision == 64) {
+        if (work_dev) { if (csg) RTC_LAUNCH_MEGA(double, true, true, scene->d64, eps, eps_rel); else RTC_LAUNCH_MEGA(double, true, false, scene->d64, eps, eps_rel); }
+        else { if (csg) RTC_LAUNCH_MEGA(double, false, true, scene->d64, eps, eps_rel); else RTC_LAUNCH_MEGA(double, false, false, scene->d64, eps, eps_rel); }
+    } else {
+        if (work_dev) { if (csg) RTC_LAUNCH_MEGA(float, true, true, scene->d32, eps, eps_rel); else RTC_LAUNCH_MEGA(float, true, false, scene->d32, eps, eps_rel); }
+        else { if (csg) RTC_LAUNCH_MEGA(float, false, true, scene->d32, eps, eps_rel); else RTC_LAUNCH_MEGA(float, false, false, scene->d32, eps, eps_rel); }
+    }
+#undef RTC_LAUNCH_MEGA
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -499,6 +613,7 @@ void rtc_scene_destroy(rtc_scene* scene) {
     if (!scene) return;
     (void)hipSetDevice(scene->device);
     scene->shared.release(); scene->mem64.release(); scene->mem32.release();
+    scene->ws_mem64.release(); scene->ws_mem32.release();
     delete scene;
 }
 

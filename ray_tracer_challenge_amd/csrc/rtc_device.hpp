@@ -17,6 +17,14 @@
 #include "../../include/rtc_api.h"
 
 #define RTC_BLOCK 256
+// __launch_bounds__ minimum waves per SIMD of the single-kernel form (register budget = 512 / waves).
+// Measured on MI355X (dragons / teapot / cover at 1080p): fp64 is fastest at 3 (168 VGPRs), fp32 at 4 (128).
+#ifndef RTC_WAVES_F64
+#define RTC_WAVES_F64 3
+#endif
+#ifndef RTC_WAVES_F32
+#define RTC_WAVES_F32 4
+#endif
 #define RTC_BVH_STACK 32      // per-lane traversal stack entries, in LDS
 #define RTC_MAX_CSG_HITS 32   // hits gathered per CSG root per ray
 #define RTC_MAX_BOUNCE_STACK 8
@@ -94,6 +102,8 @@ template <class R> __device__ __forceinline__ V3<R> xtvector(const R* __restrict
 // ------------------------------------------------------------------------------------------
 // device scene (struct of device pointers; one instance per precision)
 // ------------------------------------------------------------------------------------------
+struct alignas(64) BvhNode { float box[12]; int32_t child[2]; int32_t pad[2]; };
+
 template <class R> struct DScene {
     int32_t n_leaves;
     const int32_t* leaf_kind; const int32_t* leaf_xform; const int32_t* leaf_material;
@@ -101,9 +111,16 @@ template <class R> struct DScene {
     const R* xform;
     const R* tri_geom; const R* tri_norm; const int32_t* tri_leaf;
     int32_t n_bvh_nodes;           // 0 = no bounded items
-    const R* node_box;             // [n][12] child0 lo,hi, child1 lo,hi
-    const int32_t* node_child;     // [n][2]  >=0 inner node; <0: ~c = first<<4 | (count-1); RTC_EMPTY_CHILD = none
-    const int32_t* bvh_prims;      // prim codes in BVH leaf order
+    // one 64-byte record per node = one cache line per visit: boxes of both children in fp32 (in
+    // BOTH precisions; padded outward, see pad_boxes) and the two child references
+    // (>= 0 inner node; < 0: ~c = first<<4 | (count-1); RTC_EMPTY_CHILD = none)
+    const BvhNode* nodes;
+    const int32_t* bvh_prims;      // prim codes in BVH leaf order (analytic leaves and CSG roots only)
+    // triangles have a BVH of their own whose leaves index tb_* directly (no prim-code indirection):
+    int32_t n_tnodes;
+    const BvhNode* tnodes;
+    const R* tb_geom;              // [n_tris][12] tri_geom rows in BVH leaf order
+    const int32_t* tb_leaf;        // [n_tris] leaf id, bit 31 set = does not cast shadows
     int32_t n_unbounded; const int32_t* unbounded_prims;
     const int32_t* csg_root; const int32_t* csg_node; const R* csg_bbox;
     const R* mat; const int32_t* mat_shadow; const int32_t* mat_program;
@@ -134,13 +151,14 @@ struct DFrame {
 // visits (2 box tests each), triangle tests, analytic leaf tests, CSG root evaluations, shaded
 // hits, light samples shaded, container passes, pattern-node evaluations.
 enum { W_NODE = 0, W_TRI = 1, W_LEAF = 2, W_CSG = 3, W_SHADE = 4, W_LIGHT = 5, W_CONTAINER = 6, W_PATTERN = 7, W_COUNT = 8 };
-template <bool PROF> struct Counters {
+// CSG = false compiles the CSG branches out of every visitor (scenes without CSG objects then
+// carry none of its per-lane hit lists).
+template <bool PROF, bool CSG = true> struct Counters {
+    static constexpr bool kCsg = CSG;
     unsigned int c[4];
     unsigned int w[PROF ? W_COUNT : 1];
     __device__ __forceinline__ void work(int k) { if (PROF) w[k]++; }
 };
-template <class R> struct Bounce { V3<R> o, d, w; int remaining; };
-
 #define RTC_EPS R(0.000001) /* renderer.py:15, shapes.py:8 */
 
 // ------------------------------------------------------------------------------------------
@@ -321,32 +339,44 @@ struct PrimCode {
 
 // Visitor V: bool prim(code) -> true = stop the traversal; R limit() = current far bound.
 // Boxes are visited when their slab interval overlaps (tlo, limit()).
-template <class R, class V> __device__ __forceinline__ void traverse(const DScene<R>& S, const Ray<R>& ray, R tlo, V& vis, int* stack /* LDS, stride RTC_BLOCK */) {
-    for (int i = 0; i < S.n_unbounded; i++)
-        if (vis.prim(S.unbounded_prims[i])) return;
-    if (S.n_bvh_nodes == 0) return;
-    V3<R> inv = mk<R>(R(1) / ray.d.x, R(1) / ray.d.y, R(1) / ray.d.z);
+// TRIS = false: the object BVH (leaves hold prim codes -> vis.prim); TRIS = true: the triangle
+// BVH (leaves are ranges of tb_* rows -> vis.tri).  Returns true if the visitor stopped it.
+template <class R, class V, bool TRIS>
+__device__ __forceinline__ bool traverse_bvh(const DScene<R>& S, const Ray<R>& ray, R tlo, V& vis, int* stack /* LDS, stride RTC_BLOCK */) {
+    const BvhNode* __restrict__ nodes = TRIS ? S.tnodes : S.nodes;
+    // Box tests run in fp32 whatever R is: the boxes are padded outward by 2e-5 (relative, >= 2e-5
+    // absolute) on the host, which covers rounding the ray to fp32, and the slab distances get a
+    // 1e-5 relative slack before every comparison -- the test can only accept MORE than an exact
+    // one would, never less, so no leaf the leaf test would accept is culled.
+    const float ox = (float)ray.o.x, oy = (float)ray.o.y, oz = (float)ray.o.z;
+    const float ix = 1.0f / (float)ray.d.x, iy = 1.0f / (float)ray.d.y, iz = 1.0f / (float)ray.d.z;
+    const float tlo32 = (float)tlo;
     int sp = 0;
     int node = 0;
     while (true) {
         if (node >= 0) {
             vis.cnt.work(W_NODE);
-            const R* b = S.node_box + 12 * (size_t)node;
-            int c0 = S.node_child[2 * node], c1 = S.node_child[2 * node + 1];
-            R near[2], far[2];
+            const float4* q = reinterpret_cast<const float4*>(nodes + node);     // 4 x 16-byte loads of one line
+            const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+            const float b[12] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w};
+            int c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y);
+            float near[2], far[2];
 #pragma unroll
             for (int k = 0; k < 2; k++) {
-                const R* lo = b + 6 * k; const R* hi = lo + 3;
-                R x0 = (lo[0] - ray.o.x) * inv.x, x1 = (hi[0] - ray.o.x) * inv.x;
-                R y0 = (lo[1] - ray.o.y) * inv.y, y1 = (hi[1] - ray.o.y) * inv.y;
-                R z0 = (lo[2] - ray.o.z) * inv.z, z1 = (hi[2] - ray.o.z) * inv.z;
+                const float* lo = b + 6 * k; const float* hi = lo + 3;
+                float x0 = (lo[0] - ox) * ix, x1 = (hi[0] - ox) * ix;
+                float y0 = (lo[1] - oy) * iy, y1 = (hi[1] - oy) * iy;
+                float z0 = (lo[2] - oz) * iz, z1 = (hi[2] - oz) * iz;
                 // fmin/fmax drop the NaN of 0*inf (origin on a slab plane of a parallel ray): conservative
-                near[k] = max_(max_(min_(x0, x1), min_(y0, y1)), min_(z0, z1));
-                far[k] = min_(min_(max_(x0, x1), max_(y0, y1)), max_(z0, z1));
+                float n = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
+                float f = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
+                near[k] = n - fabsf(n) * 1e-5f;
+                far[k] = f + fabsf(f) * 1e-5f;
             }
-            R lim = vis.limit();
-            bool h0 = c0 != RTC_EMPTY_CHILD && near[0] <= far[0] && far[0] >= tlo && near[0] <= lim;
-            bool h1 = c1 != RTC_EMPTY_CHILD && near[1] <= far[1] && far[1] >= tlo && near[1] <= lim;
+            float lim = (float)vis.limit();
+            lim += fabsf(lim) * 1e-6f;
+            bool h0 = c0 != RTC_EMPTY_CHILD && near[0] <= far[0] && far[0] >= tlo32 && near[0] <= lim;
+            bool h1 = c1 != RTC_EMPTY_CHILD && near[1] <= far[1] && far[1] >= tlo32 && near[1] <= lim;
             if (h0 && h1) {
                 bool swap = near[1] < near[0];
                 int first = swap ? c1 : c0, second = swap ? c0 : c1;
@@ -359,12 +389,27 @@ template <class R, class V> __device__ __forceinline__ void traverse(const DScen
             int code = ~node;
             int first = code >> 4, count = (code & 15) + 1;
             for (int i = 0; i < count; i++)
-                if (vis.prim(S.bvh_prims[first + i])) return;
+                if (TRIS ? vis.tri(first + i) : vis.prim(S.bvh_prims[first + i])) return true;
         }
-        if (sp == 0) return;
+        if (sp == 0) return false;
         sp--;
         node = stack[sp * RTC_BLOCK];
     }
+}
+
+// the whole scene: unbounded prims, then the object BVH, then the triangle BVH (objects first, so
+// that the mesh walk starts with the tightest bound the cheap part can give)
+template <class R, class V> __device__ __forceinline__ void traverse_objects(const DScene<R>& S, const Ray<R>& ray, R tlo, V& vis, int* stack) {
+    for (int i = 0; i < S.n_unbounded; i++)
+        if (vis.prim(S.unbounded_prims[i])) return;
+    if (S.n_bvh_nodes > 0) traverse_bvh<R, V, false>(S, ray, tlo, vis, stack);
+}
+template <class R, class V> __device__ __forceinline__ void traverse_tris(const DScene<R>& S, const Ray<R>& ray, R tlo, V& vis, int* stack) {
+    if (S.n_tnodes > 0) traverse_bvh<R, V, true>(S, ray, tlo, vis, stack);
+}
+template <class R, class V> __device__ __forceinline__ void traverse(const DScene<R>& S, const Ray<R>& ray, R tlo, V& vis, int* stack) {
+    traverse_objects(S, ray, tlo, vis, stack);
+    if (!vis.done()) traverse_tris(S, ray, tlo, vis, stack);
 }
 
 // hit(intersect_world(ray)) (renderer.py:75-79, shapes.py:1422-1425): smallest t > 0
@@ -373,15 +418,18 @@ template <class R, class CNT> struct NearestVisitor {
     R best; int leaf; R u, v;
     __device__ __forceinline__ NearestVisitor(const DScene<R>& s, const Ray<R>& r, CNT& c) : S(s), ray(r), cnt(c), best(inf_<R>()), leaf(-1), u(0), v(0) {}
     __device__ __forceinline__ R limit() const { return best; }
+    __device__ __forceinline__ bool done() const { return false; }
+    __device__ __forceinline__ bool tri(int pos) {
+        R t, tu, tv;
+        cnt.work(W_TRI);
+        if (tri_hit(S.tb_geom + 12 * (size_t)pos, ray, t, tu, tv) && t > R(0) && t < best) {
+            best = t; leaf = S.tb_leaf[pos] & 0x7FFFFFFF; u = tu; v = tv;
+        }
+        return false;
+    }
     __device__ __forceinline__ bool prim(int32_t code) {
         PrimCode p(code);
-        if (p.kind == RTC_TRIANGLE) {
-            R t, tu, tv;
-            cnt.work(W_TRI);
-            if (tri_hit(S.tri_geom + 12 * (size_t)p.idx, ray, t, tu, tv) && t > R(0) && t < best) {
-                best = t; leaf = S.tri_leaf[p.idx]; u = tu; v = tv;
-            }
-        } else if (p.kind == RTC_CSG_ROOT) {
+        if (CNT::kCsg && p.kind == RTC_CSG_ROOT) {
             CsgHits<R> H;
             cnt.work(W_CSG);
             csg_hits(S, p.idx, ray, H);
@@ -409,9 +457,16 @@ template <class R, class CNT> struct ShadowVisitor {
     const DScene<R>& S; const Ray<R>& ray; CNT& cnt; R dist; bool shadowed;
     __device__ __forceinline__ ShadowVisitor(const DScene<R>& s, const Ray<R>& r, R d, CNT& c) : S(s), ray(r), cnt(c), dist(d), shadowed(false) {}
     __device__ __forceinline__ R limit() const { return dist; }
+    __device__ __forceinline__ bool done() const { return shadowed; }
+    __device__ __forceinline__ bool tri(int pos) {
+        R t, tu, tv;
+        cnt.work(W_TRI);
+        if (tri_hit(S.tb_geom + 12 * (size_t)pos, ray, t, tu, tv) && t > R(0) && t < dist && S.tb_leaf[pos] >= 0) { shadowed = true; return true; }
+        return false;
+    }
     __device__ __forceinline__ bool prim(int32_t code) {
         PrimCode p(code);
-        if (p.kind == RTC_CSG_ROOT) {
+        if (CNT::kCsg && p.kind == RTC_CSG_ROOT) {
             CsgHits<R> H;
             cnt.work(W_CSG);
             csg_hits(S, p.idx, ray, H);
@@ -420,12 +475,6 @@ template <class R, class CNT> struct ShadowVisitor {
             return false;
         }
         if (p.noshadow) return false;
-        if (p.kind == RTC_TRIANGLE) {
-            R t, tu, tv;
-            cnt.work(W_TRI);
-            if (tri_hit(S.tri_geom + 12 * (size_t)p.idx, ray, t, tu, tv) && t > R(0) && t < dist) { shadowed = true; return true; }
-            return false;
-        }
         R t[4], tu, tv;
         cnt.work(W_LEAF);
         int n = leaf_hits(S, p.idx, ray, t, tu, tv);
@@ -448,6 +497,13 @@ template <class R, class CNT> struct ContainerVisitor {
     __device__ __forceinline__ ContainerVisitor(const DScene<R>& s, const Ray<R>& r, R th, int xl, CNT& c)
         : S(s), ray(r), cnt(c), t_hit(th), x_leaf(xl), x_odd(false), x_last(-inf_<R>()), y_leaf(-1), y_last(-inf_<R>()) {}
     __device__ __forceinline__ R limit() const { return t_hit; }
+    __device__ __forceinline__ bool done() const { return false; }
+    __device__ __forceinline__ bool tri(int pos) {
+        R t, tu, tv;
+        cnt.work(W_TRI);
+        if (tri_hit(S.tb_geom + 12 * (size_t)pos, ray, t, tu, tv) && t < t_hit) account(S.tb_leaf[pos] & 0x7FFFFFFF, 1, t);
+        return false;
+    }
     __device__ __forceinline__ void account(int leaf, int count, R last) {
         if (!(count & 1)) return;
         if (leaf == x_leaf) { x_odd = true; x_last = last; }
@@ -455,7 +511,7 @@ template <class R, class CNT> struct ContainerVisitor {
     }
     __device__ __forceinline__ bool prim(int32_t code) {
         PrimCode p(code);
-        if (p.kind == RTC_CSG_ROOT) {
+        if (CNT::kCsg && p.kind == RTC_CSG_ROOT) {
             CsgHits<R> H;
             cnt.work(W_CSG);
             csg_hits(S, p.idx, ray, H);
@@ -471,9 +527,9 @@ template <class R, class CNT> struct ContainerVisitor {
             }
             return false;
         }
-        R t[4], tu, tv; int n, leaf;
-        if (p.kind == RTC_TRIANGLE) { cnt.work(W_TRI); n = tri_hit(S.tri_geom + 12 * (size_t)p.idx, ray, t[0], tu, tv) ? 1 : 0; leaf = S.tri_leaf[p.idx]; }
-        else { cnt.work(W_LEAF); leaf = p.idx; n = leaf_hits(S, leaf, ray, t, tu, tv); }
+        R t[4], tu, tv;
+        cnt.work(W_LEAF);
+        int leaf = p.idx, n = leaf_hits(S, leaf, ray, t, tu, tv);
         int cnt = 0; R last = -inf_<R>();
         for (int k = 0; k < n; k++) if (t[k] < t_hit) { cnt++; last = max_(last, t[k]); }
         account(leaf, cnt, last);
@@ -659,58 +715,163 @@ __device__ __forceinline__ V3<R> light_point(const DScene<R>& S, int l, int u, i
     return mk<R>(g[0], g[1], g[2]) + mk<R>(g[3], g[4], g[5]) * (R(u) + ju) + mk<R>(g[6], g[7], g[8]) * (R(v) + jv);
 }
 
-// shade_hit's light loop: intensity_at (renderer.py:919-922, 964-973) + lighting (:1066-1090)
-template <class R, class CNT>
-__device__ __forceinline__ V3<R> light_surface(const DScene<R>& S, int material, int leaf, V3<R> over_point, V3<R> eyev, V3<R> normalv,
-                                               int* stack, CNT& cnt, uint64_t seed, uint32_t pixel, uint32_t ray_no) {
-    const R* m = S.mat + 10 * (size_t)material;
-    R ambient = m[3], diffuse = m[4], specular = m[5], shininess = m[6];
-    if (S.mat_program[material] >= 0) cnt.work(W_PATTERN);
-    V3<R> pcolor = surface_color(S, material, leaf, over_point);
-    V3<R> surface = mk<R>(0, 0, 0);
-    for (int l = 0; l < S.n_lights; l++) {
-        const R* li = S.light_intensity + 3 * l;
-        V3<R> lint = mk<R>(li[0], li[1], li[2]);
-        V3<R> effective = pcolor * lint;
-        V3<R> amb = effective * ambient;
-        bool area = S.light_type[l] == 1;
-        int usteps = area ? S.light_steps[3 * l] : 1, vsteps = area ? S.light_steps[3 * l + 1] : 1;
-        bool jitter = area && S.light_steps[3 * l + 2] != 0;
-        int samples = usteps * vsteps;
-        // intensity_at
-        int lit = 0;
-        for (int v = 0; v < vsteps; v++)
-            for (int u = 0; u < usteps; u++) {
-                R ju = R(0.5), jv = R(0.5);
-                if (jitter) { ju = jitter01<R>(seed, pixel, ray_no, l, v * usteps + u, 0); jv = jitter01<R>(seed, pixel, ray_no, l, v * usteps + u, 1); }
-                V3<R> pos = area ? light_point(S, l, u, v, ju, jv) : mk<R>(S.light_geom[9 * l], S.light_geom[9 * l + 1], S.light_geom[9 * l + 2]);
-                if (!is_shadowed(S, pos, over_point, stack, cnt)) lit++;
-            }
-        R intensity = R(lit) / R(samples);
-        if (lit == 0) { surface = surface + amb; continue; }
-        // lighting: a FRESH set of surface points (renderer.py:1077 -> 957-962)
-        V3<R> acc = mk<R>(0, 0, 0);
-        for (int v = 0; v < vsteps; v++)
-            for (int u = 0; u < usteps; u++) {
-                R ju = R(0.5), jv = R(0.5);
-                if (jitter) { ju = jitter01<R>(seed, pixel, ray_no, l, v * usteps + u, 2); jv = jitter01<R>(seed, pixel, ray_no, l, v * usteps + u, 3); }
-                V3<R> pos = area ? light_point(S, l, u, v, ju, jv) : mk<R>(S.light_geom[9 * l], S.light_geom[9 * l + 1], S.light_geom[9 * l + 2]);
-                cnt.work(W_LIGHT);
-                V3<R> lightv = normalize(pos - over_point);
-                R ldn = dot(lightv, normalv);
-                if (ldn >= R(0)) {
-                    acc = acc + effective * diffuse * ldn;
-                    V3<R> reflectv = reflect(neg(lightv), normalv);
-                    R rde = dot(reflectv, eyev);
-                    if (rde > R(0)) acc = acc + lint * specular * pow_(rde, shininess);
-                }
-            }
-        surface = surface + amb + mk<R>(acc.x / R(samples), acc.y / R(samples), acc.z / R(samples)) * intensity;
-    }
-    return surface;
+// prepare_computations (renderer.py:206-222) for the hit (t, leaf, u, v) of `ray`
+template <class R> struct HitCtx {
+    V3<R> point, normalv, eyev, reflectv, over_point, under_point;
+    int leaf, material;
+    R t;
+};
+
+template <class R>
+__device__ __forceinline__ HitCtx<R> make_ctx(const DScene<R>& S, const Ray<R>& ray, R t, int leaf, R hu, R hv, R shade_eps, R shade_eps_rel) {
+    HitCtx<R> c;
+    c.t = t; c.leaf = leaf;
+    c.point = ray.o + ray.d * t;
+    c.normalv = normal_at(S, leaf, c.point, hu, hv);
+    c.eyev = neg(ray.d);
+    c.reflectv = reflect(ray.d, c.normalv);           // before the inside flip, like the reference
+    if (dot(c.normalv, c.eyev) < R(0)) c.normalv = neg(c.normalv);
+    // fp32: the hit point carries the rounding of o + d*t, i.e. a few ulp of the larger of |o| and |p|
+    R scale = max_(max_(max_(abs_(c.point.x), abs_(c.point.y)), abs_(c.point.z)), max_(max_(abs_(ray.o.x), abs_(ray.o.y)), abs_(ray.o.z)));
+    R eps = max_(shade_eps, shade_eps_rel * scale);
+    c.over_point = c.point + c.normalv * eps;
+    c.under_point = c.point - c.normalv * eps;
+    c.material = S.leaf_material[leaf];
+    return c;
 }
 
-// color_at for one primary ray, recursion unrolled into a stack of pending rays
+struct LightShape { bool area, jitter; int usteps, vsteps, samples; };
+template <class R> __device__ __forceinline__ LightShape light_shape(const DScene<R>& S, int l) {
+    LightShape s;
+    s.area = S.light_type[l] == 1;
+    s.usteps = s.area ? S.light_steps[3 * l] : 1;
+    s.vsteps = s.area ? S.light_steps[3 * l + 1] : 1;
+    s.jitter = s.area && S.light_steps[3 * l + 2] != 0;
+    s.samples = s.usteps * s.vsteps;
+    return s;
+}
+template <class R>
+__device__ __forceinline__ V3<R> light_sample(const DScene<R>& S, int l, const LightShape& ls, int u, int v, uint64_t seed, uint32_t pixel,
+                                              uint32_t path, uint32_t stream) {
+    if (!ls.area) return mk<R>(S.light_geom[9 * l], S.light_geom[9 * l + 1], S.light_geom[9 * l + 2]);
+    R ju = R(0.5), jv = R(0.5);
+    if (ls.jitter) { ju = jitter01<R>(seed, pixel, path, l, v * ls.usteps + u, stream); jv = jitter01<R>(seed, pixel, path, l, v * ls.usteps + u, stream + 1); }
+    return light_point(S, l, u, v, ju, jv);
+}
+
+// intensity_at * samples (renderer.py:919-922, 964-973): how many of the light's cells see `over_point`
+template <class R, class CNT>
+__device__ __forceinline__ int count_lit(const DScene<R>& S, V3<R> over_point, int l, int* stack, CNT& cnt, uint64_t seed, uint32_t pixel, uint32_t path) {
+    LightShape ls = light_shape(S, l);
+    int lit = 0;
+    for (int v = 0; v < ls.vsteps; v++)
+        for (int u = 0; u < ls.usteps; u++)
+            if (!is_shadowed(S, light_sample<R>(S, l, ls, u, v, seed, pixel, path, 0), over_point, stack, cnt)) lit++;
+    return lit;
+}
+
+// lighting (renderer.py:1066-1090) for light l given how many of its cells are unshadowed
+template <class R, class CNT>
+__device__ __forceinline__ V3<R> lighting(const DScene<R>& S, const HitCtx<R>& c, V3<R> pcolor, int l, int lit, CNT& cnt, uint64_t seed, uint32_t pixel,
+                                          uint32_t path) {
+    const R* m = S.mat + 10 * (size_t)c.material;
+    R ambient = m[3], diffuse = m[4], specular = m[5], shininess = m[6];
+    const R* li = S.light_intensity + 3 * l;
+    V3<R> lint = mk<R>(li[0], li[1], li[2]);
+    V3<R> effective = pcolor * lint;
+    V3<R> amb = effective * ambient;
+    if (lit == 0) return amb;                             // shade_intensity == 0.0: ambient only
+    LightShape ls = light_shape(S, l);
+    R intensity = R(lit) / R(ls.samples);
+    V3<R> acc = mk<R>(0, 0, 0);
+    for (int v = 0; v < ls.vsteps; v++)                   // a FRESH set of surface points (renderer.py:1077 -> 957-962)
+        for (int u = 0; u < ls.usteps; u++) {
+            V3<R> pos = light_sample<R>(S, l, ls, u, v, seed, pixel, path, 2);
+            cnt.work(W_LIGHT);
+            V3<R> lightv = normalize(pos - c.over_point);
+            R ldn = dot(lightv, c.normalv);
+            if (ldn >= R(0)) {
+                acc = acc + effective * diffuse * ldn;
+                V3<R> reflectv = reflect(neg(lightv), c.normalv);
+                R rde = dot(reflectv, c.eyev);
+                if (rde > R(0)) acc = acc + lint * specular * pow_(rde, shininess);
+            }
+        }
+    return amb + mk<R>(acc.x / R(ls.samples), acc.y / R(ls.samples), acc.z / R(ls.samples)) * intensity;
+}
+
+// n1 / n2 from what the container pass found: X = the hit leaf (in `containers` iff x_odd, entered
+// last at x_last), Y = the other odd-parity leaf entered last (at y_last), or none
+template <class R>
+__device__ __forceinline__ void container_result(const DScene<R>& S, int leaf, bool x_odd, R x_last, int y_leaf, R y_last, R& n1, R& n2) {
+    R ri_x = S.mat[10 * (size_t)S.leaf_material[leaf] + 9];
+    R ri_y = y_leaf >= 0 ? S.mat[10 * (size_t)S.leaf_material[y_leaf] + 9] : R(1);
+    if (x_odd) { n1 = (y_leaf >= 0 && y_last > x_last) ? ri_y : ri_x; n2 = ri_y; }
+    else { n1 = ri_y; n2 = ri_x; }
+}
+
+// n1 / n2 of prepare_computations (renderer.py:224-242) via the order-free container pass
+template <class R, class CNT>
+__device__ __forceinline__ void container_n1n2(const DScene<R>& S, const Ray<R>& ray, R t, int leaf, int* stack, CNT& cnt, R& n1, R& n2) {
+    cnt.work(W_CONTAINER);
+    ContainerVisitor<R, CNT> cv(S, ray, t, leaf, cnt);
+    traverse(S, ray, -inf_<R>(), cv, stack);
+    container_result(S, leaf, cv.x_odd, cv.x_last, cv.y_leaf, cv.y_last, n1, n2);
+}
+
+// What shade_hit adds on top of the surface colour (renderer.py:517-525): which secondary rays
+// exist and the factor each one's colour is multiplied by -- reflective [* reflectance] and
+// transparency [* (1 - reflectance)] -- with refracted_color's direction (renderer.py:339-350)
+// and schlick (renderer.py:272-283).
+template <class R> struct Secondary { bool refl, refr; R w_refl, w_refr; V3<R> refr_dir; };
+
+template <class R>
+__device__ __forceinline__ Secondary<R> secondary_rays(const DScene<R>& S, const HitCtx<R>& c, int remaining, R n1, R n2) {
+    const R* m = S.mat + 10 * (size_t)c.material;
+    R reflective = m[7], transparency = m[8];
+    Secondary<R> s;
+    s.refl = remaining > 0 && reflective != R(0);
+    s.refr = false;
+    s.w_refl = reflective; s.w_refr = transparency;
+    s.refr_dir = mk<R>(0, 0, 0);
+    if (remaining > 0 && transparency != R(0)) {
+        R n_ratio = n1 / n2;
+        R cos_i = dot(c.eyev, c.normalv);
+        R sin2_t = n_ratio * n_ratio * (R(1) - cos_i * cos_i);
+        if (!(sin2_t > R(1))) {
+            R cos_t = sqrt_(R(1) - sin2_t);
+            s.refr_dir = c.normalv * (n_ratio * cos_i - cos_t) - c.eyev * n_ratio;
+            s.refr = true;
+        }
+        if (reflective > R(0) && transparency > R(0)) {
+            R cosv = cos_i, reflectance;
+            bool tir = false;
+            if (n1 > n2) {
+                R n = n1 / n2;
+                R s2 = n * n * (R(1) - cosv * cosv);
+                if (s2 > R(1)) tir = true; else cosv = sqrt_(R(1) - s2);
+            }
+            if (tir) reflectance = R(1);
+            else {
+                R r0 = (n1 - n2) / (n1 + n2); r0 = r0 * r0;
+                R om = R(1) - cosv;
+                reflectance = r0 + (R(1) - r0) * (om * om * om * om * om);
+            }
+            s.w_refl *= reflectance;
+            s.w_refr *= (R(1) - reflectance);
+        }
+    }
+    return s;
+}
+__device__ __forceinline__ bool needs_containers(float transparency, int remaining) { return remaining > 0 && transparency != 0.0f; }
+__device__ __forceinline__ bool needs_containers(double transparency, int remaining) { return remaining > 0 && transparency != 0.0; }
+
+// Rays of one pixel are numbered like a binary heap: primary 1, reflection of p = 2p, refraction
+// of p = 2p + 1 (only the jitter hash uses the number).
+// color_at for one primary ray in ONE lane (the megakernel form): recursion unrolled into a
+// stack of pending rays; weights are multiplied down the tree.
+template <class R> struct Bounce { V3<R> o, d, w; int remaining; uint32_t path; };
+
 template <class R, class CNT>
 __device__ __forceinline__ V3<R> trace_pixel(const DScene<R>& S, Ray<R> primary, int max_depth, R shade_eps, R shade_eps_rel, int* stack,
                                              CNT& cnt, uint64_t seed, uint32_t pixel, int& hit_leaf_out) {
@@ -720,92 +881,40 @@ __device__ __forceinline__ V3<R> trace_pixel(const DScene<R>& S, Ray<R> primary,
     Ray<R> ray = primary;
     V3<R> weight = mk<R>(1, 1, 1);
     int remaining = max_depth;
-    uint32_t ray_no = 0;
+    uint32_t path = 1;
     hit_leaf_out = -1;
     while (true) {
         NearestVisitor<R, CNT> nv(S, ray, cnt);
         traverse(S, ray, R(0), nv, stack);
-        if (ray_no == 0) hit_leaf_out = nv.leaf;
+        if (path == 1) hit_leaf_out = nv.leaf;
         if (nv.leaf >= 0) {
-            // prepare_computations (renderer.py:206-222)
-            int leaf = nv.leaf;
-            R t = nv.best;
             cnt.work(W_SHADE);
-            V3<R> point = ray.o + ray.d * t;
-            V3<R> normalv = normal_at(S, leaf, point, nv.u, nv.v);
-            V3<R> eyev = neg(ray.d);
-            V3<R> reflectv = reflect(ray.d, normalv);
-            if (dot(normalv, eyev) < R(0)) normalv = neg(normalv);
-            // fp32: the hit point carries the rounding of o + d*t, i.e. a few ulp of the larger of |o| and |p|
-            R scale = max_(max_(max_(abs_(point.x), abs_(point.y)), abs_(point.z)), max_(max_(abs_(ray.o.x), abs_(ray.o.y)), abs_(ray.o.z)));
-            R eps = max_(shade_eps, shade_eps_rel * scale);
-            V3<R> over_point = point + normalv * eps;
-            V3<R> under_point = point - normalv * eps;
-            int material = S.leaf_material[leaf];
-            const R* m = S.mat + 10 * (size_t)material;
-            R reflective = m[7], transparency = m[8];
-
-            V3<R> surface = light_surface(S, material, leaf, over_point, eyev, normalv, stack, cnt, seed, pixel, ray_no);
+            HitCtx<R> c = make_ctx(S, ray, nv.best, nv.leaf, nv.u, nv.v, shade_eps, shade_eps_rel);
+            if (S.mat_program[c.material] >= 0) cnt.work(W_PATTERN);
+            V3<R> pcolor = surface_color(S, c.material, c.leaf, c.over_point);
+            V3<R> surface = mk<R>(0, 0, 0);
+            for (int l = 0; l < S.n_lights; l++) {
+                int lit = count_lit(S, c.over_point, l, stack, cnt, seed, pixel, path);
+                surface = surface + lighting(S, c, pcolor, l, lit, cnt, seed, pixel, path);
+            }
             color = color + weight * surface;
-
-            if (remaining > 0 && (reflective != R(0) || transparency != R(0))) {
-                R wrefl = reflective, wrefr = transparency;
-                bool do_refr = false;
-                V3<R> refr_dir = mk<R>(0, 0, 0);
-                if (transparency != R(0)) {
-                    // n1 / n2 (renderer.py:224-242) via the order-free container pass
-                    cnt.work(W_CONTAINER);
-                    ContainerVisitor<R, CNT> cv(S, ray, t, leaf, cnt);
-                    traverse(S, ray, -inf_<R>(), cv, stack);
-                    R ri_x = m[9];
-                    R ri_y = cv.y_leaf >= 0 ? S.mat[10 * (size_t)S.leaf_material[cv.y_leaf] + 9] : R(1);
-                    R n1, n2;
-                    if (cv.x_odd) { n1 = (cv.y_leaf >= 0 && cv.y_last > cv.x_last) ? ri_y : ri_x; n2 = ri_y; }
-                    else { n1 = ri_y; n2 = ri_x; }
-                    // refracted_color (renderer.py:339-350)
-                    R n_ratio = n1 / n2;
-                    R cos_i = dot(eyev, normalv);
-                    R sin2_t = n_ratio * n_ratio * (R(1) - cos_i * cos_i);
-                    if (!(sin2_t > R(1))) {
-                        R cos_t = sqrt_(R(1) - sin2_t);
-                        refr_dir = normalv * (n_ratio * cos_i - cos_t) - eyev * n_ratio;
-                        do_refr = true;
-                    }
-                    if (reflective > R(0) && transparency > R(0)) {
-                        // schlick (renderer.py:272-283)
-                        R cosv = cos_i, reflectance;
-                        bool tir = false;
-                        if (n1 > n2) {
-                            R n = n1 / n2;
-                            R s2 = n * n * (R(1) - cosv * cosv);
-                            if (s2 > R(1)) tir = true; else cosv = sqrt_(R(1) - s2);
-                        }
-                        if (tir) reflectance = R(1);
-                        else {
-                            R r0 = (n1 - n2) / (n1 + n2); r0 = r0 * r0;
-                            R om = R(1) - cosv;
-                            reflectance = r0 + (R(1) - r0) * (om * om * om * om * om);
-                        }
-                        wrefl *= reflectance;
-                        wrefr *= (R(1) - reflectance);
-                    }
-                }
-                if (do_refr && np < RTC_MAX_BOUNCE_STACK) {
-                    Bounce<R> b = {under_point, refr_dir, weight * wrefr, remaining - 1};
-                    pending[np++] = b;
-                    cnt.c[3]++;
-                }
-                if (reflective != R(0) && np < RTC_MAX_BOUNCE_STACK) {
-                    Bounce<R> b = {over_point, reflectv, weight * wrefl, remaining - 1};
-                    pending[np++] = b;
-                    cnt.c[2]++;
-                }
+            R n1 = R(1), n2 = R(1);
+            if (needs_containers(S.mat[10 * (size_t)c.material + 8], remaining)) container_n1n2(S, ray, c.t, c.leaf, stack, cnt, n1, n2);
+            Secondary<R> sec = secondary_rays(S, c, remaining, n1, n2);
+            if (sec.refr && np < RTC_MAX_BOUNCE_STACK) {
+                Bounce<R> b = {c.under_point, sec.refr_dir, weight * sec.w_refr, remaining - 1, 2 * path + 1};
+                pending[np++] = b;
+                cnt.c[3]++;
+            }
+            if (sec.refl && np < RTC_MAX_BOUNCE_STACK) {
+                Bounce<R> b = {c.over_point, c.reflectv, weight * sec.w_refl, remaining - 1, 2 * path};
+                pending[np++] = b;
+                cnt.c[2]++;
             }
         }
         if (np == 0) break;
         np--;
-        ray.o = pending[np].o; ray.d = pending[np].d; weight = pending[np].w; remaining = pending[np].remaining;
-        ray_no++;
+        ray.o = pending[np].o; ray.d = pending[np].d; weight = pending[np].w; remaining = pending[np].remaining; path = pending[np].path;
     }
     return color;
 }

@@ -231,3 +231,19 @@ def test_nested_and_blended_patterns_and_nested_csg(oracle_cls):
     # fine stripes / rings / checkers on a plane seen at a grazing angle: fp32 flips the pattern cell on
     # boundary pixels, which is inherent to the precision; this is a torture scene, not a BASELINE config
     assert frac_off_by_more_than_one(got32, want) <= 0.02
+
+
+@pytest.mark.parametrize("name,size", [("cover", None), ("csg_test", (160, 160)), ("shadow_glamour_shot_nojitter", (120, 48)),
+                                       ("teapot", None), ("dragons", (480, 192))])
+def test_wavefront_pipeline_matches_single_kernel(name, size, scenes):
+    """RTC_FLAG_WAVEFRONT (rays in HBM queues, one sweep of kernels per bounce level) traces the same rays."""
+    cam, world, sc = scenes(name)
+    if size:
+        cam = cam.resized(*size)
+    for prec, tol in (("fp64", 1e-12), ("fp32", 1e-5)):
+        s1, s2 = {}, {}
+        a, ia = sc.render(cam, precision=prec, want_ids=True, stats=s1)
+        b, ib = sc.render(cam, precision=prec, want_ids=True, stats=s2, wavefront=True)
+        np.testing.assert_allclose(a, b, rtol=0, atol=tol)
+        np.testing.assert_array_equal(ia, ib)
+        assert s1["rays"] == s2["rays"]
