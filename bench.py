@@ -41,9 +41,9 @@ def algorithmic_flops(work):
 
 def algorithmic_bytes(work, real_bytes):
     node, tri, leaf = work[0], work[1], work[2]
-    # a node visit reads both child boxes (12 reals) + 2 child refs; a triangle test p1,e1,e2,eps (10 reals);
-    # an analytic leaf test its 3x4 (12 reals)
-    return node * (12 * real_bytes + 8) + tri * 10 * real_bytes + leaf * 12 * real_bytes
+    # a node visit reads one 64-byte node (both child boxes as 12 fp32 + 2 child refs, in either precision);
+    # a triangle test p1,e1,e2,eps (10 reals); an analytic leaf test its 3x4 (12 reals)
+    return node * 64 + tri * 10 * real_bytes + leaf * 12 * real_bytes
 
 
 def main():
@@ -179,7 +179,7 @@ def main():
                      "kernel_ms": round(kms32, 4)},
             "roofline": {"bound": "valu", "achieved": round(achieved, 4), "peak": PEAK_TFLOPS["fp64"], "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_TFLOPS["fp64"], 5), "traffic": traffic,
-                         "kernel": "trace_kernel<double>", "kernel_ms": round(kms64, 4),
+                         "kernel": "trace_kernel<double, false, %s>" % ("true" if cs.counts.get("n_csg_roots") else "false"), "kernel_ms": round(kms64, 4),
                          "algorithmic_flops_per_launch": flops, "algorithmic_bytes_per_launch": algorithmic_bytes(work, 8),
                          "work_per_launch": dict(zip(["bvh_node_visits", "triangle_tests", "analytic_leaf_tests", "csg_evals",
                                                       "shaded_hits", "light_samples", "container_passes", "pattern_evals"], work))},

@@ -40,7 +40,7 @@ int fail(int code, const char* fmt, ...) {
 // kernels
 // ---------------------------------------------------------------------------------------------
 template <class R, bool PROF, bool CSG>
-__global__ __launch_bounds__(RTC_BLOCK, (sizeof(R) == 8 ? RTC_WAVES_F64 : RTC_WAVES_F32)) void trace_kernel(rtc::DScene<R> S, rtc::DCamera<R> cam, rtc::DFrame F, R shade_eps, R shade_eps_rel) {
+__global__ __launch_bounds__(RTC_BLOCK, (CSG ? 2 : sizeof(R) == 8 ? RTC_WAVES_F64 : RTC_WAVES_F32)) void trace_kernel(rtc::DScene<R> S, rtc::DCamera<R> cam, rtc::DFrame F, R shade_eps, R shade_eps_rel) {
     __shared__ int s_stack[RTC_BVH_STACK * RTC_BLOCK];
     int* stack = s_stack + threadIdx.x;
     const int T = F.tile_size, per_tile = T * T, sub = T / 8;

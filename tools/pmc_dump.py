@@ -1,4 +1,4 @@
-import sqlite3, sys
+import re, sqlite3, sys
 from collections import defaultdict
 c = sqlite3.connect(sys.argv[1])
 rows = list(c.execute("select dispatch_id, kernel_name, counter_name, value, grid_size from counters_collection order by dispatch_id"))
@@ -6,9 +6,10 @@ by = defaultdict(dict)
 names = {}
 for d, k, cn, v, g in rows:
     by[d][cn] = by[d].get(cn, 0) + v
-    names[d] = (k.split('(')[0].split('::')[-1][:28], g)
+    m = re.search(r'(trace_kernel<[^>]*>|wf_\w+|quantize_kernel)', k)
+    names[d] = ((m.group(1) if m else k)[:34], g)
 keys = sorted({cn for d in by for cn in by[d]})
-print("%-30s %9s " % ("kernel", "grid") + " ".join("%14s" % k[-14:] for k in keys))
+print("%-36s %9s " % ("kernel", "grid") + " ".join("%14s" % k[-14:] for k in keys))
 sel = [d for d in sorted(by) if 'wf_' in names[d][0] or 'trace_kernel' in names[d][0]]
 for d in sel[-int(sys.argv[2]) if len(sys.argv) > 2 else 0:]:
-    print("%-30s %9d " % names[d] + " ".join("%14.0f" % by[d].get(k, 0) for k in keys))
+    print("%-36s %9d " % names[d] + " ".join("%14.0f" % by[d].get(k, 0) for k in keys))

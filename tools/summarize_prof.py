@@ -32,7 +32,7 @@ for sub in ("pmc_fetch", "pmc_write", "pmc_sq"):
         short = k[k.index("trace_kernel"):k.index("(rtc")]
         out.append("%-28s %-22s n=%-3d avg=%.1f" % (short, cn, n, avg))
         traffic.setdefault(short, {})[cn] = avg
-k64 = traffic.get("trace_kernel<double, false>", {})
+k64 = next((v for k, v in traffic.items() if k.startswith("trace_kernel<double, false")), {})
 if "FETCH_SIZE" in k64 and "WRITE_SIZE" in k64:
     js = {"source": "profiles/%s_pmc.txt" % tag,
           "fetch_bytes_raw_fp64": k64["FETCH_SIZE"] * 1024, "write_bytes_fp64": k64["WRITE_SIZE"] * 1024,
