@@ -136,9 +136,14 @@ typedef struct {
  * accounting, never for timing). */
 #define RTC_FLAG_COUNT_WORK 1
 /* Use the wavefront pipeline (rays in HBM queues, one sweep of small kernels per bounce level)
- * instead of the default single kernel (one lane = one pixel, in-lane bounce stack).  Same
- * results to rounding; slower on every scene measured so far, kept for A/B measurements. */
+ * instead of the default form.  Same results to rounding; slower on every scene measured so
+ * far, kept for A/B measurements. */
 #define RTC_FLAG_WAVEFRONT 2
+/* The single kernel records how long every wave (8x8 pixel block) took and the next frame on the
+ * same scene handle launches the dearest blocks first (any order gives the same image; a good
+ * one shortens the tail of the launch).  This flag renders in plain tile order and leaves the
+ * recorded costs alone. */
+#define RTC_FLAG_NO_FEEDBACK 8
 
 typedef struct {
     int32_t precision;   /* 64 = fp64 (reference arithmetic), 32 = fp32 throughput mode */

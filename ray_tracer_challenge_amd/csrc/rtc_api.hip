@@ -43,34 +43,59 @@ template <class R, bool PROF, bool CSG>
 __global__ __launch_bounds__(RTC_BLOCK, (CSG ? 2 : sizeof(R) == 8 ? RTC_WAVES_F64 : RTC_WAVES_F32)) void trace_kernel(rtc::DScene<R> S, rtc::DCamera<R> cam, rtc::DFrame F, R shade_eps, R shade_eps_rel) {
     __shared__ int s_stack[RTC_BVH_STACK * RTC_BLOCK];
     int* stack = s_stack + threadIdx.x;
-    const int T = F.tile_size, per_tile = T * T, sub = T / 8;
-    long long w = (long long)blockIdx.x * RTC_BLOCK + threadIdx.x;
-    int slot = (int)(w / per_tile), within = (int)(w % per_tile);
+    long long unit = (long long)blockIdx.x * (RTC_BLOCK / 64) + (threadIdx.x >> 6);   // one wave = one unit = one 8x8 pixel block
+    const long long t_start = F.cost ? (long long)wall_clock64() : 0;
+    if (F.order) unit = unit < F.n_units ? F.order[unit] : -1;
+    if (unit >= F.n_units) unit = -1;
+    long long w = unit * 64 + (threadIdx.x & 63);
     rtc::Counters<PROF, CSG> cnt;
     rtc::zero_counters(cnt);
-    if (slot < F.n_tiles) {
-        int tile = F.tile_ids ? F.tile_ids[slot] : slot;
-        int tx0 = (tile % F.tiles_x) * T, ty0 = (tile / F.tiles_x) * T;
-        int sb = within >> 6, l = within & 63;          // one wave = one 8x8 pixel block
-        int x = tx0 + (sb % sub) * 8 + (l & 7), y = ty0 + (sb / sub) * 8 + (l >> 3);
-        if (x < cam.hsize && y < cam.vsize) {
-            rtc::Ray<R> ray = rtc::ray_for_pixel(cam, x, y);
-            cnt.c[0] = 1;
-            int hit_leaf;
-            rtc::V3<R> c = rtc::trace_pixel(S, ray, F.max_depth, shade_eps, shade_eps_rel, stack, cnt, F.seed,
-                                            (uint32_t)(y * cam.hsize + x), hit_leaf);
-            size_t o;
-            if (F.tile_ids) {
-                int lx = x - tx0, ly = y - ty0;
-                o = (size_t)slot * per_tile + (size_t)ly * T + lx;
-            } else {
-                o = (size_t)x * cam.vsize + y;   // canvas order [x][y] (canvas.py:60)
-            }
-            F.rgb[3 * o] = (double)c.x; F.rgb[3 * o + 1] = (double)c.y; F.rgb[3 * o + 2] = (double)c.z;
-            if (F.hit_id) F.hit_id[o] = hit_leaf;
-        }
+    int x, y;
+    size_t o;
+    if (unit >= 0 && rtc::wf_pixel(F, cam.hsize, cam.vsize, w, x, y, o)) {
+        rtc::Ray<R> ray = rtc::ray_for_pixel(cam, x, y);
+        cnt.c[0] = 1;
+        int hit_leaf;
+#ifdef RTC_TIMELINE
+        long long tl_start = wall_clock64();
+#endif
+        rtc::V3<R> c = rtc::trace_pixel(S, ray, F.max_depth, shade_eps, shade_eps_rel, stack, cnt, F.seed,
+                                        (uint32_t)(y * cam.hsize + x), hit_leaf);
+#ifdef RTC_TIMELINE   /* development build only (tools/timeline.py): start/end ticks (100 MHz) instead of the colour */
+        c.x = (R)(double)(tl_start & 0xFFFFFFFFFFLL); c.y = (R)(double)(wall_clock64() & 0xFFFFFFFFFFLL); c.z = R(0);
+#endif
+        F.rgb[3 * o] = (double)c.x; F.rgb[3 * o + 1] = (double)c.y; F.rgb[3 * o + 2] = (double)c.z;
+        if (F.hit_id) F.hit_id[o] = hit_leaf;
+    }
+    if (F.cost && unit >= 0 && (threadIdx.x & 63) == 0) {
+        long long dt = (long long)wall_clock64() - t_start;
+        F.cost[unit] = (uint32_t)(dt < 0 ? 0 : dt > 0x7FFFFFFFLL ? 0x7FFFFFFFLL : dt);
     }
     rtc::flush_counters(cnt, F, reinterpret_cast<unsigned int*>(s_stack));
+}
+
+// Next frame's launch order from this frame's wave costs: units in descending cost, by buckets of a
+// quarter octave (one block; n is a few 10^4).  The order inside a bucket is whatever the atomics
+// give -- any permutation renders the same image.
+#define RTC_ORDER_BUCKETS 128
+__global__ __launch_bounds__(1024) void order_kernel(const uint32_t* cost, int32_t* order, int n) {
+    __shared__ unsigned int hist[RTC_ORDER_BUCKETS], cursor[RTC_ORDER_BUCKETS];
+    for (int b = threadIdx.x; b < RTC_ORDER_BUCKETS; b += blockDim.x) hist[b] = 0;
+    __syncthreads();
+    auto bucket = [](uint32_t c) {
+        int lg = 31 - __clz((int)(c | 1u));                              // floor(log2 c)
+        int frac = lg >= 2 ? (int)((c >> (lg - 2)) & 3u) : 0;            // next two bits: quarter octaves
+        int b = 4 * lg + frac;
+        return RTC_ORDER_BUCKETS - 1 - (b > RTC_ORDER_BUCKETS - 1 ? RTC_ORDER_BUCKETS - 1 : b);   // dearest first
+    };
+    for (int i = threadIdx.x; i < n; i += blockDim.x) atomicAdd(&hist[bucket(cost[i])], 1u);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned int run = 0;
+        for (int b = 0; b < RTC_ORDER_BUCKETS; b++) { cursor[b] = run; run += hist[b]; }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += blockDim.x) order[atomicAdd(&cursor[bucket(cost[i])], 1u)] = i;
 }
 
 // canvas.py:133-156
@@ -159,6 +184,15 @@ struct rtc_scene {
     double ws_factor = 6.0;   // pool capacity in rays per level-0 work item
     int last_overflow = 0;
     int mask_words = 1;       // 32-bit words of shadow bits per (ray, light): ceil(max light samples / 32)
+    // launch-order feedback of the single-kernel form: per-unit cost of the last frame, two order buffers
+    DeviceArena fb_mem;
+    uint32_t* fb_cost = nullptr; int32_t* fb_order[2] = {nullptr, nullptr};
+    long long fb_units = 0; int fb_cur = 0; bool fb_valid = false;
+    // what the current order was measured on, and how many frames of it have been sorted: the order
+    // is rebuilt after the first two frames of a view (the second one measured under the new order)
+    // and then kept until the view changes
+    struct FbKey { rtc_camera cam; int32_t precision, depth, tile_size, n_tiles; const int32_t* tile_ids; } fb_key{};
+    int fb_age = 0;
 };
 
 namespace {
@@ -374,6 +408,9 @@ int create_impl(const rtc_scene_desc& d, rtc_scene* sc) {
     }
     if (int rc = upload_real<double>(d, bvh.box, sc->mem64, sc->d64)) return rc;
     if (int rc = upload_real<float>(d, bvh.box, sc->mem32, sc->d32)) return rc;
+    if ((sc->d64.n_bvh_nodes > 0 && (!sc->d64.nodes || !sc->d64.bvh_prims || !sc->d32.nodes)) ||
+        (sc->d64.n_tnodes > 0 && (!sc->d64.tnodes || !sc->d64.tb_geom || !sc->d64.tb_leaf || !sc->d32.tnodes || !sc->d32.tb_geom)))
+        return fail(RTC_ERR_HIP, "internal: BVH arrays missing on the device");
     sc->has_csg = d.n_csg_roots > 0;
     for (int i = 0; i < d.n_lights; i++) {
         if (d.light_type[i] == 1 && d.light_steps[3 * i + 2]) sc->has_jitter = true;
@@ -488,6 +525,10 @@ int launch(rtc_scene* scene, const rtc_camera* cam, const rtc_render_opts* opts,
     long long blocks = (work + RTC_BLOCK - 1) / RTC_BLOCK;
     if (blocks > 0x7FFFFFFFLL) return fail(RTC_ERR_LIMIT, "too many blocks");
     F.work = reinterpret_cast<unsigned long long*>(work_dev);
+    F.order = nullptr; F.cost = nullptr;
+    const long long n_units = blocks * (RTC_BLOCK / 64);
+    if (n_units > 0x7FFFFFFFLL) return fail(RTC_ERR_LIMIT, "too many blocks");
+    F.n_units = (int32_t)n_units;
     const bool wavefront = opts && (opts->flags & RTC_FLAG_WAVEFRONT);
     if (wavefront) {
         std::lock_guard<std::mutex> lock(scene->ws_mutex);
@@ -505,6 +546,30 @@ int launch(rtc_scene* scene, const rtc_camera* cam, const rtc_render_opts* opts,
     }
     dim3 grid((unsigned)blocks), block(RTC_BLOCK);
     const bool csg = scene->has_csg;
+    const bool feedback = !(opts && (opts->flags & RTC_FLAG_NO_FEEDBACK));
+    std::unique_lock<std::mutex> fb_lock(scene->ws_mutex, std::defer_lock);
+    bool resort = false;
+    if (feedback) {
+        fb_lock.lock();
+        if (scene->fb_units != n_units) {
+            scene->fb_mem.release(); scene->fb_mem.bytes = 0; scene->fb_units = 0; scene->fb_valid = false;
+            void* p = nullptr;
+            HIP_TRY(hipMalloc(&p, (size_t)n_units * sizeof(uint32_t))); scene->fb_mem.ptrs.push_back(p); scene->fb_cost = (uint32_t*)p;
+            for (int k = 0; k < 2; k++) {
+                HIP_TRY(hipMalloc(&p, (size_t)n_units * sizeof(int32_t))); scene->fb_mem.ptrs.push_back(p); scene->fb_order[k] = (int32_t*)p;
+            }
+            scene->fb_mem.bytes = (size_t)n_units * 12;
+            scene->fb_units = n_units;
+        }
+        rtc_scene::FbKey key;
+        memset(&key, 0, sizeof(key));
+        key.cam = *cam; key.precision = precision; key.depth = depth; key.tile_size = T; key.n_tiles = n_tiles; key.tile_ids = tile_ids_dev;
+        if (memcmp(&key, &scene->fb_key, sizeof(key)) != 0) { scene->fb_key = key; scene->fb_age = 0; }
+        resort = scene->fb_age < 2;
+        scene->fb_age++;
+        F.cost = resort ? scene->fb_cost : nullptr;
+        F.order = scene->fb_valid ? scene->fb_order[scene->fb_cur] : nullptr;
+    }
 #define RTC_LAUNCH_MEGA(R, PROF, CSG, SC, EPS, EPSREL) \
     hipLaunchKernelGGL((trace_kernel<R, PROF, CSG>), grid, block, 0, stream, SC, make_camera<R>(*cam), F, (R)(EPS), (R)(EPSREL))
     if (precision == 64) {
@@ -516,6 +581,14 @@ int launch(rtc_scene* scene, const rtc_camera* cam, const rtc_render_opts* opts,
     }
 #undef RTC_LAUNCH_MEGA
     HIP_TRY(hipGetLastError());
+    if (feedback && resort) {
+        // this frame's costs -> the order the next frame on this scene launches in (other buffer: the
+        // kernel above may still be reading the current one)
+        hipLaunchKernelGGL(order_kernel, dim3(1), dim3(1024), 0, stream, scene->fb_cost, scene->fb_order[1 - scene->fb_cur], (int)n_units);
+        HIP_TRY(hipGetLastError());
+        scene->fb_cur = 1 - scene->fb_cur;
+        scene->fb_valid = true;
+    }
     return 0;
 }
 
@@ -613,7 +686,7 @@ void rtc_scene_destroy(rtc_scene* scene) {
     if (!scene) return;
     (void)hipSetDevice(scene->device);
     scene->shared.release(); scene->mem64.release(); scene->mem32.release();
-    scene->ws_mem64.release(); scene->ws_mem32.release();
+    scene->ws_mem64.release(); scene->ws_mem32.release(); scene->fb_mem.release();
     delete scene;
 }
 

@@ -16,7 +16,9 @@
 
 #include "../../include/rtc_api.h"
 
+#ifndef RTC_BLOCK
 #define RTC_BLOCK 256
+#endif
 // __launch_bounds__ minimum waves per SIMD of the single-kernel form (register budget = 512 / waves).
 // Measured on MI355X (dragons / teapot / cover at 1080p): fp64 is fastest at 3 (168 VGPRs), fp32 at 4 (128).
 #ifndef RTC_WAVES_F64
@@ -25,7 +27,9 @@
 #ifndef RTC_WAVES_F32
 #define RTC_WAVES_F32 4
 #endif
+#ifndef RTC_BVH_STACK
 #define RTC_BVH_STACK 32      // per-lane traversal stack entries, in LDS
+#endif
 #define RTC_MAX_CSG_HITS 32   // hits gathered per CSG root per ray
 #define RTC_MAX_BOUNCE_STACK 8
 #define RTC_PAT_STACK 6
@@ -145,6 +149,10 @@ struct DFrame {
     double* rgb; int32_t* hit_id; unsigned long long* rays; unsigned long long* work;
     int32_t max_depth;
     uint64_t seed;
+    // launch-order feedback (single-kernel form; both NULL = plain order): unit = one wave = 64 work items
+    const int32_t* order;        // [n_units] permutation: the k-th wave launched renders unit order[k]
+    uint32_t* cost;              // [n_units] wall-clock ticks the wave that rendered the unit took
+    int32_t n_units;
 };
 
 // c: rays traced (primary, shadow, reflection, refraction).  w (PROF builds only): BVH node
@@ -356,6 +364,9 @@ __device__ __forceinline__ bool traverse_bvh(const DScene<R>& S, const Ray<R>& r
     while (true) {
         if (node >= 0) {
             vis.cnt.work(W_NODE);
+#ifdef RTC_LANE_STATS   /* development build: W_PATTERN counts wave-level node iterations (x 65536) instead */
+            if (sizeof(vis.cnt.w) > 4) vis.cnt.w[W_PATTERN] += 65536u / (unsigned)__popcll(__ballot(1));
+#endif
             const float4* q = reinterpret_cast<const float4*>(nodes + node);     // 4 x 16-byte loads of one line
             const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
             const float b[12] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w};
@@ -886,18 +897,15 @@ __device__ __forceinline__ V3<R> trace_pixel(const DScene<R>& S, Ray<R> primary,
     while (true) {
         NearestVisitor<R, CNT> nv(S, ray, cnt);
         traverse(S, ray, R(0), nv, stack);
-        if (path == 1) hit_leaf_out = nv.leaf;
-        if (nv.leaf >= 0) {
+        const R hit_t = nv.best, hit_u = nv.u, hit_v = nv.v;
+        const int hit_leaf = nv.leaf;
+        if (path == 1) hit_leaf_out = hit_leaf;
+        if (hit_leaf >= 0) {
             cnt.work(W_SHADE);
-            HitCtx<R> c = make_ctx(S, ray, nv.best, nv.leaf, nv.u, nv.v, shade_eps, shade_eps_rel);
+            HitCtx<R> c = make_ctx(S, ray, hit_t, hit_leaf, hit_u, hit_v, shade_eps, shade_eps_rel);
             if (S.mat_program[c.material] >= 0) cnt.work(W_PATTERN);
-            V3<R> pcolor = surface_color(S, c.material, c.leaf, c.over_point);
-            V3<R> surface = mk<R>(0, 0, 0);
-            for (int l = 0; l < S.n_lights; l++) {
-                int lit = count_lit(S, c.over_point, l, stack, cnt, seed, pixel, path);
-                surface = surface + lighting(S, c, pcolor, l, lit, cnt, seed, pixel, path);
-            }
-            color = color + weight * surface;
+            // the secondary rays go onto the pending stack BEFORE the light loop, so that what only they
+            // need (reflectv, under_point, the ray itself, t) is dead while the shadow rays are walked
             R n1 = R(1), n2 = R(1);
             if (needs_containers(S.mat[10 * (size_t)c.material + 8], remaining)) container_n1n2(S, ray, c.t, c.leaf, stack, cnt, n1, n2);
             Secondary<R> sec = secondary_rays(S, c, remaining, n1, n2);
@@ -911,6 +919,13 @@ __device__ __forceinline__ V3<R> trace_pixel(const DScene<R>& S, Ray<R> primary,
                 pending[np++] = b;
                 cnt.c[2]++;
             }
+            V3<R> pcolor = surface_color(S, c.material, c.leaf, c.over_point);
+            V3<R> surface = mk<R>(0, 0, 0);
+            for (int l = 0; l < S.n_lights; l++) {
+                int lit = count_lit(S, c.over_point, l, stack, cnt, seed, pixel, path);
+                surface = surface + lighting(S, c, pcolor, l, lit, cnt, seed, pixel, path);
+            }
+            color = color + weight * surface;
         }
         if (np == 0) break;
         np--;

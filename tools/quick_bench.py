@@ -28,12 +28,14 @@ for lib in libs:
         cam, cs = scenes[name]
         with _ffi.Scene(cs) as sc:
             row = []
-            for prec, mega in ((("fp64", False), ("fp64", True), ("fp32", False), ("fp32", True)) if os.environ.get("QB_WF") else (("fp64", True), ("fp32", True))):
+            forms = [("fb", {}), ("nofb", {"feedback": False})] + ([("wf", {"wavefront": True})] if os.environ.get("QB_WF") else [])
+            for prec, mega in [(p_, f_) for p_ in ("fp64", "fp32") for f_ in forms]:
                 ms = []
                 for it in range(6):
                     st = {}
-                    rgb, _ = sc.render(cam, precision=prec, stats=st, wavefront=not mega)
+                    rgb, _ = sc.render(cam, precision=prec, stats=st, **mega[1])
                     ms.append(st["kernel_ms"])
+                mega = mega[0]
                 key = (name, prec, mega)
                 same = ""
                 if key in ref:
@@ -41,5 +43,9 @@ for lib in libs:
                 else:
                     ref[key] = rgb
                 rays = sum(st["rays"])
-                row.append("%s%s %7.3f ms %8.1f Mr/s%s" % (prec, "M" if mega else "W", min(ms[1:]), rays / min(ms[1:]) / 1e3, same))
+                if mega == "fb":
+                    base = rgb
+                else:
+                    same += " =fb" if np.array_equal(base, rgb) else " !=fb(%d px)" % int((np.abs(base - rgb).max(axis=2) > 1e-9).sum())
+                row.append("%s/%s %6.3f ms%s" % (prec, mega, min(ms[1:]), same))
         print("  %-30s %s" % (name, " | ".join(row)), flush=True)
