@@ -139,10 +139,16 @@ typedef struct {
  * instead of the default form.  Same results to rounding; slower on every scene measured so
  * far, kept for A/B measurements. */
 #define RTC_FLAG_WAVEFRONT 2
-/* The single kernel records how long every wave (8x8 pixel block) took and the next frame on the
- * same scene handle launches the dearest blocks first (any order gives the same image; a good
- * one shortens the tail of the launch).  This flag renders in plain tile order and leaves the
- * recorded costs alone. */
+/* Trace every pixel's whole ray tree in one lane (one kernel per frame) even when the scene has
+ * reflective or transparent materials.  The default for such scenes is the level pipeline: one
+ * kernel per bounce level over a pool of rays in HBM, so that a pixel's rays run side by side
+ * instead of one after the other.  Same rays, same per-ray arithmetic; a pixel's contributions
+ * are added in tree order instead of as a running sum (differences of an ulp or two). */
+#define RTC_FLAG_SINGLE_KERNEL 4
+/* The primary-ray kernel records how long every wave (8x8 pixel block) took and the next frames of
+ * the same view on the same scene handle launch the dearest blocks first (any order gives the
+ * same image; a good one shortens the tail of the launch).  This flag renders in plain tile
+ * order and leaves the recorded costs alone. */
 #define RTC_FLAG_NO_FEEDBACK 8
 
 typedef struct {

@@ -14,7 +14,7 @@
 #include "../../include/rtc_api.h"
 #include "rtc_bvh.hpp"
 #include "rtc_device.hpp"
-#include "rtc_wavefront.hpp"
+#include "rtc_levels.hpp"
 
 namespace {
 
@@ -43,16 +43,14 @@ template <class R, bool PROF, bool CSG>
 __global__ __launch_bounds__(RTC_BLOCK, (CSG ? 2 : sizeof(R) == 8 ? RTC_WAVES_F64 : RTC_WAVES_F32)) void trace_kernel(rtc::DScene<R> S, rtc::DCamera<R> cam, rtc::DFrame F, R shade_eps, R shade_eps_rel) {
     __shared__ int s_stack[RTC_BVH_STACK * RTC_BLOCK];
     int* stack = s_stack + threadIdx.x;
-    long long unit = (long long)blockIdx.x * (RTC_BLOCK / 64) + (threadIdx.x >> 6);   // one wave = one unit = one 8x8 pixel block
-    const long long t_start = F.cost ? (long long)wall_clock64() : 0;
-    if (F.order) unit = unit < F.n_units ? F.order[unit] : -1;
-    if (unit >= F.n_units) unit = -1;
-    long long w = unit * 64 + (threadIdx.x & 63);
+    const int lane = threadIdx.x & 63;
     rtc::Counters<PROF, CSG> cnt;
     rtc::zero_counters(cnt);
+    const long long t_start = F.cost ? (long long)wall_clock64() : 0;
+    const long long unit = rtc::wave_unit(F);
     int x, y;
     size_t o;
-    if (unit >= 0 && rtc::wf_pixel(F, cam.hsize, cam.vsize, w, x, y, o)) {
+    if (unit >= 0 && rtc::wf_pixel(F, cam.hsize, cam.vsize, unit * 64 + lane, x, y, o)) {
         rtc::Ray<R> ray = rtc::ray_for_pixel(cam, x, y);
         cnt.c[0] = 1;
         int hit_leaf;
@@ -67,35 +65,36 @@ __global__ __launch_bounds__(RTC_BLOCK, (CSG ? 2 : sizeof(R) == 8 ? RTC_WAVES_F6
         F.rgb[3 * o] = (double)c.x; F.rgb[3 * o + 1] = (double)c.y; F.rgb[3 * o + 2] = (double)c.z;
         if (F.hit_id) F.hit_id[o] = hit_leaf;
     }
-    if (F.cost && unit >= 0 && (threadIdx.x & 63) == 0) {
+    if (F.cost && unit >= 0 && lane == 0) {
         long long dt = (long long)wall_clock64() - t_start;
         F.cost[unit] = (uint32_t)(dt < 0 ? 0 : dt > 0x7FFFFFFFLL ? 0x7FFFFFFFLL : dt);
     }
     rtc::flush_counters(cnt, F, reinterpret_cast<unsigned int*>(s_stack));
 }
 
-// Next frame's launch order from this frame's wave costs: units in descending cost, by buckets of a
-// quarter octave (one block; n is a few 10^4).  The order inside a bucket is whatever the atomics
-// give -- any permutation renders the same image.
+// Next frame's launch order from this frame's unit costs (one block; n is a few 10^4): units in
+// descending cost by buckets of a quarter octave -- the launch cannot end before its longest wave
+// does, so the long ones go first.  The order inside a bucket is whatever the atomics give; any
+// order renders the same image.
 #define RTC_ORDER_BUCKETS 128
+__device__ __forceinline__ int order_bucket(uint32_t c) {
+    int lg = 31 - __clz((int)(c | 1u));                              // floor(log2 c)
+    int frac = lg >= 2 ? (int)((c >> (lg - 2)) & 3u) : 0;            // next two bits: quarter octaves
+    int b = 4 * lg + frac;
+    return RTC_ORDER_BUCKETS - 1 - (b > RTC_ORDER_BUCKETS - 1 ? RTC_ORDER_BUCKETS - 1 : b);   // dearest first
+}
 __global__ __launch_bounds__(1024) void order_kernel(const uint32_t* cost, int32_t* order, int n) {
     __shared__ unsigned int hist[RTC_ORDER_BUCKETS], cursor[RTC_ORDER_BUCKETS];
     for (int b = threadIdx.x; b < RTC_ORDER_BUCKETS; b += blockDim.x) hist[b] = 0;
     __syncthreads();
-    auto bucket = [](uint32_t c) {
-        int lg = 31 - __clz((int)(c | 1u));                              // floor(log2 c)
-        int frac = lg >= 2 ? (int)((c >> (lg - 2)) & 3u) : 0;            // next two bits: quarter octaves
-        int b = 4 * lg + frac;
-        return RTC_ORDER_BUCKETS - 1 - (b > RTC_ORDER_BUCKETS - 1 ? RTC_ORDER_BUCKETS - 1 : b);   // dearest first
-    };
-    for (int i = threadIdx.x; i < n; i += blockDim.x) atomicAdd(&hist[bucket(cost[i])], 1u);
+    for (int i = threadIdx.x; i < n; i += blockDim.x) atomicAdd(&hist[order_bucket(cost[i])], 1u);
     __syncthreads();
     if (threadIdx.x == 0) {
         unsigned int run = 0;
         for (int b = 0; b < RTC_ORDER_BUCKETS; b++) { cursor[b] = run; run += hist[b]; }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < n; i += blockDim.x) order[atomicAdd(&cursor[bucket(cost[i])], 1u)] = i;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) order[atomicAdd(&cursor[order_bucket(cost[i])], 1u)] = i;
 }
 
 // canvas.py:133-156
@@ -188,9 +187,15 @@ struct rtc_scene {
     DeviceArena fb_mem;
     uint32_t* fb_cost = nullptr; int32_t* fb_order[2] = {nullptr, nullptr};
     long long fb_units = 0; int fb_cur = 0; bool fb_valid = false;
+    int n_cus = 0;
     // what the current order was measured on, and how many frames of it have been sorted: the order
     // is rebuilt after the first two frames of a view (the second one measured under the new order)
     // and then kept until the view changes
+    // ray pool of the level pipeline (sized for fp64, shared by both precisions), grown on demand
+    DeviceArena lv_mem;
+    void* lv_ray = nullptr; double* lv_col = nullptr; int32_t* lv_kids = nullptr; int32_t* lv_kids0 = nullptr; rtc::LvCtrl* lv_ctrl = nullptr;
+    long long lv_cap = 0, lv_work = 0;
+    bool has_secondary = false;   // some material reflects or refracts
     struct FbKey { rtc_camera cam; int32_t precision, depth, tile_size, n_tiles; const int32_t* tile_ids; } fb_key{};
     int fb_age = 0;
 };
@@ -313,6 +318,11 @@ int validate(const rtc_scene_desc& d) {
 }
 
 int create_impl(const rtc_scene_desc& d, rtc_scene* sc) {
+    {
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, sc->device));
+        sc->n_cus = prop.multiProcessorCount;
+    }
     // ---- two BVHs over the bounded items (host): analytic leaves + CSG roots, and triangles ----
     std::vector<rtc::Aabb> obox, tbox;
     std::vector<int32_t> oprim, tprim;
@@ -412,6 +422,8 @@ int create_impl(const rtc_scene_desc& d, rtc_scene* sc) {
         (sc->d64.n_tnodes > 0 && (!sc->d64.tnodes || !sc->d64.tb_geom || !sc->d64.tb_leaf || !sc->d32.tnodes || !sc->d32.tb_geom)))
         return fail(RTC_ERR_HIP, "internal: BVH arrays missing on the device");
     sc->has_csg = d.n_csg_roots > 0;
+    for (int i = 0; i < d.n_materials; i++)
+        if (d.mat[10 * (size_t)i + 7] != 0.0 || d.mat[10 * (size_t)i + 8] != 0.0) sc->has_secondary = true;
     for (int i = 0; i < d.n_lights; i++) {
         if (d.light_type[i] == 1 && d.light_steps[3 * i + 2]) sc->has_jitter = true;
         if (d.light_type[i] == 1) sc->mask_words = std::max(sc->mask_words, (d.light_steps[3 * i] * d.light_steps[3 * i + 1] + 31) / 32);
@@ -544,32 +556,71 @@ int launch(rtc_scene* scene, const rtc_camera* cam, const rtc_render_opts* opts,
         if (work_dev) return run_wavefront<float, true>(scene->d32, make_camera<float>(*cam), scene->ws32, F, (float)eps, (float)eps_rel, work, stream);
         return run_wavefront<float, false>(scene->d32, make_camera<float>(*cam), scene->ws32, F, (float)eps, (float)eps_rel, work, stream);
     }
-    dim3 grid((unsigned)blocks), block(RTC_BLOCK);
+    dim3 block(RTC_BLOCK);
     const bool csg = scene->has_csg;
     const bool feedback = !(opts && (opts->flags & RTC_FLAG_NO_FEEDBACK));
-    std::unique_lock<std::mutex> fb_lock(scene->ws_mutex, std::defer_lock);
+    const int waves_per_simd = csg ? 2 : (precision == 64 ? RTC_WAVES_F64 : RTC_WAVES_F32);
+    dim3 grid((unsigned)blocks);
+    std::lock_guard<std::mutex> fb_lock(scene->ws_mutex);
     bool resort = false;
-    if (feedback) {
-        fb_lock.lock();
-        if (scene->fb_units != n_units) {
-            scene->fb_mem.release(); scene->fb_mem.bytes = 0; scene->fb_units = 0; scene->fb_valid = false;
-            void* p = nullptr;
-            HIP_TRY(hipMalloc(&p, (size_t)n_units * sizeof(uint32_t))); scene->fb_mem.ptrs.push_back(p); scene->fb_cost = (uint32_t*)p;
-            for (int k = 0; k < 2; k++) {
-                HIP_TRY(hipMalloc(&p, (size_t)n_units * sizeof(int32_t))); scene->fb_mem.ptrs.push_back(p); scene->fb_order[k] = (int32_t*)p;
-            }
-            scene->fb_mem.bytes = (size_t)n_units * 12;
-            scene->fb_units = n_units;
+    if (scene->fb_units != n_units) {
+        scene->fb_mem.release(); scene->fb_mem.bytes = 0; scene->fb_units = 0; scene->fb_valid = false;
+        void* p = nullptr;
+        HIP_TRY(hipMalloc(&p, (size_t)n_units * sizeof(uint32_t))); scene->fb_mem.ptrs.push_back(p); scene->fb_cost = (uint32_t*)p;
+        for (int k = 0; k < 2; k++) {
+            HIP_TRY(hipMalloc(&p, (size_t)n_units * sizeof(int32_t))); scene->fb_mem.ptrs.push_back(p); scene->fb_order[k] = (int32_t*)p;
         }
+        scene->fb_mem.bytes = (size_t)n_units * 12;
+        scene->fb_units = n_units;
+    }
+    if (feedback) {
         rtc_scene::FbKey key;
         memset(&key, 0, sizeof(key));
         key.cam = *cam; key.precision = precision; key.depth = depth; key.tile_size = T; key.n_tiles = n_tiles; key.tile_ids = tile_ids_dev;
         if (memcmp(&key, &scene->fb_key, sizeof(key)) != 0) { scene->fb_key = key; scene->fb_age = 0; }
         resort = scene->fb_age < 2;
         scene->fb_age++;
-        F.cost = resort ? scene->fb_cost : nullptr;
-        F.order = scene->fb_valid ? scene->fb_order[scene->fb_cur] : nullptr;
+        if (resort) F.cost = scene->fb_cost;
+        if (scene->fb_valid) F.order = scene->fb_order[scene->fb_cur];
     }
+    // the level pipeline wherever there are secondary rays to spread out; the single kernel otherwise
+    const bool levels = scene->has_secondary && depth > 0 && !(opts && (opts->flags & RTC_FLAG_SINGLE_KERNEL));
+    if (levels) {
+        const long long n_work = blocks * RTC_BLOCK;
+        long long cap = 3 * n_work + 65536;
+        if (cap > 0x1FFFFFFFLL) cap = 0x1FFFFFFFLL;
+        if (scene->lv_cap < cap || scene->lv_work < n_work) {
+            scene->lv_mem.release(); scene->lv_mem.bytes = 0; scene->lv_cap = 0; scene->lv_work = 0;
+            void* p = nullptr;
+#define LV_ALLOC(field, type, count) do { size_t sz_ = (size_t)(count) * sizeof(type); HIP_TRY(hipMalloc(&p, sz_)); scene->lv_mem.ptrs.push_back(p); scene->lv_mem.bytes += sz_; scene->field = static_cast<decltype(scene->field)>(p); } while (0)
+            LV_ALLOC(lv_ray, rtc::LvRay<double>, cap);
+            LV_ALLOC(lv_col, double, 3 * cap);
+            LV_ALLOC(lv_kids, int32_t, cap);
+            LV_ALLOC(lv_kids0, int32_t, n_work);
+            LV_ALLOC(lv_ctrl, rtc::LvCtrl, 1);
+#undef LV_ALLOC
+            scene->lv_cap = cap; scene->lv_work = n_work;
+        }
+        HIP_TRY(hipMemsetAsync(scene->lv_ctrl, 0, sizeof(rtc::LvCtrl), stream));
+        const unsigned level_grid = (unsigned)std::min<long long>((cap + RTC_BLOCK - 1) / RTC_BLOCK, (long long)scene->n_cus * waves_per_simd);
+#define RTC_LAUNCH_LEVELS(R, PROF, CSG, SC, EPS, EPSREL) do { \
+        rtc::LvSpace<R> Q; \
+        Q.ray = static_cast<rtc::LvRay<R>*>(scene->lv_ray); Q.col = scene->lv_col; Q.kids = scene->lv_kids; Q.kids0 = scene->lv_kids0; \
+        Q.ctrl = scene->lv_ctrl; Q.cap = (int32_t)scene->lv_cap; \
+        hipLaunchKernelGGL((rtc::lv_primary<R, PROF, CSG>), grid, block, 0, stream, SC, make_camera<R>(*cam), F, (R)(EPS), (R)(EPSREL), Q); \
+        for (int L = 1; L <= depth; L++) \
+            hipLaunchKernelGGL((rtc::lv_level<R, PROF, CSG>), dim3(level_grid), block, 0, stream, SC, F, (R)(EPS), (R)(EPSREL), Q, L); \
+        hipLaunchKernelGGL((rtc::lv_redo<R, PROF, CSG>), dim3(level_grid), block, 0, stream, SC, make_camera<R>(*cam), F, (R)(EPS), (R)(EPSREL), Q, n_work, depth); \
+        hipLaunchKernelGGL((rtc::lv_gather<R>), dim3((unsigned)blocks), block, 0, stream, F, cam->hsize, cam->vsize, Q, n_work); } while (0)
+        if (precision == 64) {
+            if (work_dev) { if (csg) RTC_LAUNCH_LEVELS(double, true, true, scene->d64, eps, eps_rel); else RTC_LAUNCH_LEVELS(double, true, false, scene->d64, eps, eps_rel); }
+            else { if (csg) RTC_LAUNCH_LEVELS(double, false, true, scene->d64, eps, eps_rel); else RTC_LAUNCH_LEVELS(double, false, false, scene->d64, eps, eps_rel); }
+        } else {
+            if (work_dev) { if (csg) RTC_LAUNCH_LEVELS(float, true, true, scene->d32, eps, eps_rel); else RTC_LAUNCH_LEVELS(float, true, false, scene->d32, eps, eps_rel); }
+            else { if (csg) RTC_LAUNCH_LEVELS(float, false, true, scene->d32, eps, eps_rel); else RTC_LAUNCH_LEVELS(float, false, false, scene->d32, eps, eps_rel); }
+        }
+#undef RTC_LAUNCH_LEVELS
+    } else {
 #define RTC_LAUNCH_MEGA(R, PROF, CSG, SC, EPS, EPSREL) \
     hipLaunchKernelGGL((trace_kernel<R, PROF, CSG>), grid, block, 0, stream, SC, make_camera<R>(*cam), F, (R)(EPS), (R)(EPSREL))
     if (precision == 64) {
@@ -580,6 +631,7 @@ int launch(rtc_scene* scene, const rtc_camera* cam, const rtc_render_opts* opts,
         else { if (csg) RTC_LAUNCH_MEGA(float, false, true, scene->d32, eps, eps_rel); else RTC_LAUNCH_MEGA(float, false, false, scene->d32, eps, eps_rel); }
     }
 #undef RTC_LAUNCH_MEGA
+    }
     HIP_TRY(hipGetLastError());
     if (feedback && resort) {
         // this frame's costs -> the order the next frame on this scene launches in (other buffer: the
@@ -686,7 +738,7 @@ void rtc_scene_destroy(rtc_scene* scene) {
     if (!scene) return;
     (void)hipSetDevice(scene->device);
     scene->shared.release(); scene->mem64.release(); scene->mem32.release();
-    scene->ws_mem64.release(); scene->ws_mem32.release(); scene->fb_mem.release();
+    scene->ws_mem64.release(); scene->ws_mem32.release(); scene->fb_mem.release(); scene->lv_mem.release();
     delete scene;
 }
 

@@ -149,11 +149,21 @@ struct DFrame {
     double* rgb; int32_t* hit_id; unsigned long long* rays; unsigned long long* work;
     int32_t max_depth;
     uint64_t seed;
-    // launch-order feedback (single-kernel form; both NULL = plain order): unit = one wave = 64 work items
-    const int32_t* order;        // [n_units] permutation: the k-th wave launched renders unit order[k]
-    uint32_t* cost;              // [n_units] wall-clock ticks the wave that rendered the unit took
+    // Launch order of the pixel kernels: unit = 64 work items = one 8x8 pixel block = one wave's job; the
+    // k-th wave of the grid renders unit order[k] (blocks are dispatched in index order, so the first
+    // entries start first).
     int32_t n_units;
+    const int32_t* order;        // [n_units] a permutation of the units, or NULL = 0, 1, 2, ...
+    uint32_t* cost;              // [n_units] wall-clock ticks the unit took, or NULL = do not record
 };
+
+// the unit of this wave, -1 if there is none
+__device__ __forceinline__ long long wave_unit(const DFrame& F) {
+    long long entry = (long long)blockIdx.x * (RTC_BLOCK / 64) + (threadIdx.x >> 6);
+    if (entry >= F.n_units) return -1;
+    int u = F.order ? F.order[entry] : (int)entry;
+    return (u < 0 || u >= F.n_units) ? -1 : u;
+}
 
 // c: rays traced (primary, shadow, reflection, refraction).  w (PROF builds only): BVH node
 // visits (2 box tests each), triangle tests, analytic leaf tests, CSG root evaluations, shaded
@@ -879,59 +889,85 @@ __device__ __forceinline__ bool needs_containers(double transparency, int remain
 
 // Rays of one pixel are numbered like a binary heap: primary 1, reflection of p = 2p, refraction
 // of p = 2p + 1 (only the jitter hash uses the number).
-// color_at for one primary ray in ONE lane (the megakernel form): recursion unrolled into a
-// stack of pending rays; weights are multiplied down the tree.
+
+// color_at's body for ONE ray (renderer.py:527-566 without the recursion): nearest hit,
+// prepare_computations, the secondary rays shade_hit would recurse into -- handed to `emit`
+// BEFORE the light loop, so that what only they need (reflectv, under_point, the ray itself, t)
+// is dead while the shadow rays are walked -- and the surface colour from every light.
+// emit(has_refl, refl_origin, refl_dir, refl_factor, has_refr, refr_origin, refr_dir, refr_factor)
+// is called once for every ray that hits something; if it returns false the ray is given up here
+// (its caller will have it traced again some other way) and the light loop is skipped.
+template <class R, class CNT, class EMIT>
+__device__ __forceinline__ V3<R> shade_ray(const DScene<R>& S, const Ray<R>& ray, int remaining, uint32_t path, R shade_eps, R shade_eps_rel,
+                                           int* stack, CNT& cnt, uint64_t seed, uint32_t pixel, int& hit_leaf, EMIT& emit) {
+    NearestVisitor<R, CNT> nv(S, ray, cnt);
+    traverse(S, ray, R(0), nv, stack);
+    hit_leaf = nv.leaf;
+    V3<R> surface = mk<R>(0, 0, 0);
+    if (nv.leaf >= 0) {
+        cnt.work(W_SHADE);
+        HitCtx<R> c = make_ctx(S, ray, nv.best, nv.leaf, nv.u, nv.v, shade_eps, shade_eps_rel);
+        if (S.mat_program[c.material] >= 0) cnt.work(W_PATTERN);
+        R n1 = R(1), n2 = R(1);
+        if (needs_containers(S.mat[10 * (size_t)c.material + 8], remaining)) container_n1n2(S, ray, c.t, c.leaf, stack, cnt, n1, n2);
+        Secondary<R> sec = secondary_rays(S, c, remaining, n1, n2);
+        if (!emit(sec.refl, c.over_point, c.reflectv, sec.w_refl, sec.refr, c.under_point, sec.refr_dir, sec.w_refr)) return surface;
+        V3<R> pcolor = surface_color(S, c.material, c.leaf, c.over_point);
+        for (int l = 0; l < S.n_lights; l++) {
+            int lit = count_lit(S, c.over_point, l, stack, cnt, seed, pixel, path);
+            surface = surface + lighting(S, c, pcolor, l, lit, cnt, seed, pixel, path);
+        }
+    }
+    return surface;
+}
+
+// The whole ray tree under one ray in ONE lane: recursion unrolled into a stack of pending rays;
+// weights are multiplied down the tree.  Returns sum of weight * surface over the tree.
 template <class R> struct Bounce { V3<R> o, d, w; int remaining; uint32_t path; };
 
+template <class R, class CNT> struct PushPending {
+    Bounce<R>* pending; int& np; const V3<R>& weight; const int& remaining; const uint32_t& path; CNT& cnt;
+    __device__ __forceinline__ bool operator()(bool refl, V3<R> refl_o, V3<R> refl_d, R w_refl, bool refr, V3<R> refr_o, V3<R> refr_d, R w_refr) {
+        if (refr && np < RTC_MAX_BOUNCE_STACK) {
+            Bounce<R> b = {refr_o, refr_d, weight * w_refr, remaining - 1, 2 * path + 1};
+            pending[np++] = b;
+            cnt.c[3]++;
+        }
+        if (refl && np < RTC_MAX_BOUNCE_STACK) {
+            Bounce<R> b = {refl_o, refl_d, weight * w_refl, remaining - 1, 2 * path};
+            pending[np++] = b;
+            cnt.c[2]++;
+        }
+        return true;
+    }
+};
+
 template <class R, class CNT>
-__device__ __forceinline__ V3<R> trace_pixel(const DScene<R>& S, Ray<R> primary, int max_depth, R shade_eps, R shade_eps_rel, int* stack,
-                                             CNT& cnt, uint64_t seed, uint32_t pixel, int& hit_leaf_out) {
+__device__ __forceinline__ V3<R> trace_tree(const DScene<R>& S, Ray<R> ray, V3<R> weight, int remaining, uint32_t path, R shade_eps,
+                                            R shade_eps_rel, int* stack, CNT& cnt, uint64_t seed, uint32_t pixel, int& first_leaf) {
     Bounce<R> pending[RTC_MAX_BOUNCE_STACK];
     int np = 0;
     V3<R> color = mk<R>(0, 0, 0);
-    Ray<R> ray = primary;
-    V3<R> weight = mk<R>(1, 1, 1);
-    int remaining = max_depth;
-    uint32_t path = 1;
-    hit_leaf_out = -1;
+    bool first = true;
+    first_leaf = -1;
     while (true) {
-        NearestVisitor<R, CNT> nv(S, ray, cnt);
-        traverse(S, ray, R(0), nv, stack);
-        const R hit_t = nv.best, hit_u = nv.u, hit_v = nv.v;
-        const int hit_leaf = nv.leaf;
-        if (path == 1) hit_leaf_out = hit_leaf;
-        if (hit_leaf >= 0) {
-            cnt.work(W_SHADE);
-            HitCtx<R> c = make_ctx(S, ray, hit_t, hit_leaf, hit_u, hit_v, shade_eps, shade_eps_rel);
-            if (S.mat_program[c.material] >= 0) cnt.work(W_PATTERN);
-            // the secondary rays go onto the pending stack BEFORE the light loop, so that what only they
-            // need (reflectv, under_point, the ray itself, t) is dead while the shadow rays are walked
-            R n1 = R(1), n2 = R(1);
-            if (needs_containers(S.mat[10 * (size_t)c.material + 8], remaining)) container_n1n2(S, ray, c.t, c.leaf, stack, cnt, n1, n2);
-            Secondary<R> sec = secondary_rays(S, c, remaining, n1, n2);
-            if (sec.refr && np < RTC_MAX_BOUNCE_STACK) {
-                Bounce<R> b = {c.under_point, sec.refr_dir, weight * sec.w_refr, remaining - 1, 2 * path + 1};
-                pending[np++] = b;
-                cnt.c[3]++;
-            }
-            if (sec.refl && np < RTC_MAX_BOUNCE_STACK) {
-                Bounce<R> b = {c.over_point, c.reflectv, weight * sec.w_refl, remaining - 1, 2 * path};
-                pending[np++] = b;
-                cnt.c[2]++;
-            }
-            V3<R> pcolor = surface_color(S, c.material, c.leaf, c.over_point);
-            V3<R> surface = mk<R>(0, 0, 0);
-            for (int l = 0; l < S.n_lights; l++) {
-                int lit = count_lit(S, c.over_point, l, stack, cnt, seed, pixel, path);
-                surface = surface + lighting(S, c, pcolor, l, lit, cnt, seed, pixel, path);
-            }
-            color = color + weight * surface;
-        }
+        int leaf;
+        PushPending<R, CNT> push = {pending, np, weight, remaining, path, cnt};
+        V3<R> surface = shade_ray(S, ray, remaining, path, shade_eps, shade_eps_rel, stack, cnt, seed, pixel, leaf, push);
+        if (first) { first_leaf = leaf; first = false; }
+        if (leaf >= 0) color = color + weight * surface;
         if (np == 0) break;
         np--;
         ray.o = pending[np].o; ray.d = pending[np].d; weight = pending[np].w; remaining = pending[np].remaining; path = pending[np].path;
     }
     return color;
+}
+
+// color_at for one primary ray (the single-kernel form)
+template <class R, class CNT>
+__device__ __forceinline__ V3<R> trace_pixel(const DScene<R>& S, Ray<R> primary, int max_depth, R shade_eps, R shade_eps_rel, int* stack,
+                                             CNT& cnt, uint64_t seed, uint32_t pixel, int& hit_leaf_out) {
+    return trace_tree(S, primary, mk<R>(1, 1, 1), max_depth, 1u, shade_eps, shade_eps_rel, stack, cnt, seed, pixel, hit_leaf_out);
 }
 
 // renderer.py:742-751
