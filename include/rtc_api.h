@@ -135,17 +135,14 @@ typedef struct {
 /* Run the instrumented kernel variant that also counts work items (slower; for roofline
  * accounting, never for timing). */
 #define RTC_FLAG_COUNT_WORK 1
-/* Use the wavefront pipeline (rays in HBM queues, one sweep of small kernels per bounce level)
- * instead of the default form.  Same results to rounding; slower on every scene measured so
- * far, kept for A/B measurements. */
+/* Use the level pipeline instead of the default single kernel: one kernel per bounce level over
+ * a pool of rays in HBM (each secondary ray is its own work item, children appended with one
+ * atomic per wave), then a depth-first gather that adds every pixel's subtree in a fixed order.
+ * Same rays and per-ray arithmetic; a pixel's contributions are added in tree order instead of
+ * as a running sum (an ulp or two).  Slower than the single kernel on every scene measured (each
+ * level pays the full latency of one ray's traversals with few rays in flight); kept for A/B. */
 #define RTC_FLAG_WAVEFRONT 2
-/* Trace every pixel's whole ray tree in one lane (one kernel per frame) even when the scene has
- * reflective or transparent materials.  The default for such scenes is the level pipeline: one
- * kernel per bounce level over a pool of rays in HBM, so that a pixel's rays run side by side
- * instead of one after the other.  Same rays, same per-ray arithmetic; a pixel's contributions
- * are added in tree order instead of as a running sum (differences of an ulp or two). */
-#define RTC_FLAG_SINGLE_KERNEL 4
-/* The primary-ray kernel records how long every wave (8x8 pixel block) took and the next frames of
+/* The pixel kernel records how long every wave (8x8 pixel block) took and the next frames of
  * the same view on the same scene handle launch the dearest blocks first (any order gives the
  * same image; a good one shortens the tail of the launch).  This flag renders in plain tile
  * order and leaves the recorded costs alone. */

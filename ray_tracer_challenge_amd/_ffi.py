@@ -128,11 +128,11 @@ def make_camera(cam):
 
 
 def make_opts(precision="fp64", max_depth=5, tile_size=32, shade_eps=0.0, seed=0, count_work=False, shade_eps_rel=-1.0,
-              wavefront=False, feedback=True, single_kernel=False):
+              wavefront=False, feedback=True):
     bits = {"fp64": 64, "fp32": 32, 64: 64, 32: 32}.get(precision)
     if bits is None:
         raise ValueError("precision must be 'fp64' or 'fp32'")
-    return RenderOpts(bits, int(max_depth), int(tile_size), (1 if count_work else 0) | (2 if wavefront else 0) | (0 if feedback else 8) | (4 if single_kernel else 0), float(shade_eps), float(shade_eps_rel), int(seed))
+    return RenderOpts(bits, int(max_depth), int(tile_size), (1 if count_work else 0) | (2 if wavefront else 0) | (0 if feedback else 8), float(shade_eps), float(shade_eps_rel), int(seed))
 
 
 def make_desc(cs):
@@ -179,9 +179,9 @@ class Scene(object):
         return {k: getattr(out, k) for k, _ in SceneInfo._fields_}
 
     def render(self, cam, precision="fp64", max_depth=5, want_ids=False, stats=None, shade_eps=0.0, seed=0,
-               count_work=False, wavefront=False, feedback=True, single_kernel=False):
+               count_work=False, wavefront=False, feedback=True):
         """-> (rgb (hsize, vsize, 3) f64, ids (hsize, vsize) i32 or None)."""
-        c, o, st = make_camera(cam), make_opts(precision, max_depth, 32, shade_eps, seed, count_work, wavefront=wavefront, feedback=feedback, single_kernel=single_kernel), Stats()
+        c, o, st = make_camera(cam), make_opts(precision, max_depth, 32, shade_eps, seed, count_work, wavefront=wavefront, feedback=feedback), Stats()
         rgb = np.zeros((c.hsize, c.vsize, 3), np.float64)
         ids = np.full((c.hsize, c.vsize), -1, np.int32) if want_ids else None
         _check(lib().rtc_render(self.handle, C.byref(c), C.byref(o), rgb.ctypes.data_as(_P),
@@ -190,9 +190,9 @@ class Scene(object):
         return rgb, ids
 
     def render_tiles(self, cam, tile_ids, precision="fp64", max_depth=5, tile_size=32, want_ids=False, stats=None,
-                     shade_eps=0.0, seed=0, wavefront=False, feedback=True, single_kernel=False):
+                     shade_eps=0.0, seed=0, wavefront=False, feedback=True):
         """Compact tiles -> (rgb (n, T, T, 3) [slot][ty][tx], ids (n, T, T) or None)."""
-        c, o, st = make_camera(cam), make_opts(precision, max_depth, tile_size, shade_eps, seed, wavefront=wavefront, feedback=feedback, single_kernel=single_kernel), Stats()
+        c, o, st = make_camera(cam), make_opts(precision, max_depth, tile_size, shade_eps, seed, wavefront=wavefront, feedback=feedback), Stats()
         tiles = np.ascontiguousarray(tile_ids, dtype=np.int32)
         n, T = tiles.size, tile_size
         rgb = np.zeros((n, T, T, 3), np.float64)
@@ -203,9 +203,9 @@ class Scene(object):
         return rgb, ids
 
     def render_device(self, cam, rgb_ptr, ids_ptr=None, rays_ptr=None, tile_ids_ptr=None, n_tiles=0, precision="fp64",
-                      max_depth=5, tile_size=32, shade_eps=0.0, seed=0, stream=None, count_work=False, wavefront=False, feedback=True, single_kernel=False):
+                      max_depth=5, tile_size=32, shade_eps=0.0, seed=0, stream=None, count_work=False, wavefront=False, feedback=True):
         """Asynchronous launch on device pointers (ints, e.g. torch `tensor.data_ptr()`)."""
-        c, o = make_camera(cam), make_opts(precision, max_depth, tile_size, shade_eps, seed, count_work, wavefront=wavefront, feedback=feedback, single_kernel=single_kernel)
+        c, o = make_camera(cam), make_opts(precision, max_depth, tile_size, shade_eps, seed, count_work, wavefront=wavefront, feedback=feedback)
         _check(lib().rtc_render_device(self.handle, C.byref(c), C.byref(o), int(n_tiles), _P(tile_ids_ptr or None),
                                        _P(rgb_ptr), _P(ids_ptr or None), _P(rays_ptr or None), _P(stream or None)))
 

@@ -50,7 +50,7 @@ __global__ __launch_bounds__(RTC_BLOCK, (CSG ? 2 : sizeof(R) == 8 ? RTC_WAVES_F6
     const long long unit = rtc::wave_unit(F);
     int x, y;
     size_t o;
-    if (unit >= 0 && rtc::wf_pixel(F, cam.hsize, cam.vsize, unit * 64 + lane, x, y, o)) {
+    if (unit >= 0 && rtc::work_pixel(F, cam.hsize, cam.vsize, unit * 64 + lane, x, y, o)) {
         rtc::Ray<R> ray = rtc::ray_for_pixel(cam, x, y);
         cnt.c[0] = 1;
         int hit_leaf;
@@ -174,15 +174,7 @@ struct rtc_scene {
     rtc::DScene<double> d64;
     rtc::DScene<float> d32;
     bool has_jitter = false, has_csg = false;
-    // wavefront ray pools, one per precision, grown on demand and reused across frames
-    std::mutex ws_mutex;
-    DeviceArena ws_mem64, ws_mem32;
-    rtc::WfSpace<double> ws64{};
-    rtc::WfSpace<float> ws32{};
-    int ws_lights64 = 0, ws_lights32 = 0;
-    double ws_factor = 6.0;   // pool capacity in rays per level-0 work item
-    int last_overflow = 0;
-    int mask_words = 1;       // 32-bit words of shadow bits per (ray, light): ceil(max light samples / 32)
+    std::mutex ws_mutex;      // guards the per-scene workspaces below
     // launch-order feedback of the single-kernel form: per-unit cost of the last frame, two order buffers
     DeviceArena fb_mem;
     uint32_t* fb_cost = nullptr; int32_t* fb_order[2] = {nullptr, nullptr};
@@ -426,7 +418,6 @@ int create_impl(const rtc_scene_desc& d, rtc_scene* sc) {
         if (d.mat[10 * (size_t)i + 7] != 0.0 || d.mat[10 * (size_t)i + 8] != 0.0) sc->has_secondary = true;
     for (int i = 0; i < d.n_lights; i++) {
         if (d.light_type[i] == 1 && d.light_steps[3 * i + 2]) sc->has_jitter = true;
-        if (d.light_type[i] == 1) sc->mask_words = std::max(sc->mask_words, (d.light_steps[3 * i] * d.light_steps[3 * i + 1] + 31) / 32);
     }
     return 0;
 }
@@ -456,68 +447,6 @@ int check_render_args(const rtc_scene* scene, const rtc_camera* cam, const rtc_r
     return 0;
 }
 
-__global__ void wf_init(rtc::WfCtrl* ctrl, int n0) {
-    for (int k = 0; k < RTC_WF_MAX_LEVELS; k++) ctrl->count[k] = 0;
-    ctrl->count[0] = n0;
-    ctrl->overflow = 0;
-}
-
-template <class R>
-int ensure_workspace(rtc::WfSpace<R>& W, DeviceArena& A, int& have_lights, long long cap, int n_lights, int mask_words) {
-    if (W.ray && W.cap >= cap && have_lights >= n_lights * mask_words) { W.mask_words = mask_words; return 0; }
-    A.release();
-    A.bytes = 0;
-    memset(&W, 0, sizeof(W));
-    size_t n = (size_t)cap, nl = (size_t)std::max(1, n_lights * mask_words);
-#define WS_ALLOC(field, type, count) do { void* p_ = nullptr; size_t sz_ = (count) * sizeof(type); HIP_TRY(hipMalloc(&p_, sz_)); A.ptrs.push_back(p_); A.bytes += sz_; W.field = static_cast<type*>(p_); } while (0)
-    WS_ALLOC(ray, rtc::WfRay<R>, n);
-    WS_ALLOC(hit, rtc::WfHit<R>, n);
-    WS_ALLOC(pix, int32_t, n);
-    WS_ALLOC(link, rtc::WfLink<R>, n);
-    WS_ALLOC(col, rtc::WfCol<R>, n);
-    WS_ALLOC(cst, rtc::WfCst<R>, n);
-    WS_ALLOC(opt, rtc::WfPt<R>, n);
-    WS_ALLOC(mask, uint32_t, n * nl);
-    WS_ALLOC(ctrl, rtc::WfCtrl, 1);
-#undef WS_ALLOC
-    W.cap = (int32_t)cap;
-    W.mask_words = mask_words;
-    have_lights = (int)nl;
-    return 0;
-}
-
-template <class R, bool PROF>
-int run_wavefront(const rtc::DScene<R>& S, const rtc::DCamera<R>& cam, rtc::WfSpace<R>& W, const rtc::DFrame& F, R eps, R eps_rel,
-                  long long n0, hipStream_t stream) {
-    rtc::WfParams<R> P;
-    P.W = W; P.F = F; P.shade_eps = eps; P.shade_eps_rel = eps_rel; P.level = 0;
-    const int D = F.max_depth;
-    const unsigned fixed = 2048;                       // grid-stride grid for levels whose size only the GPU knows
-    dim3 block(RTC_BLOCK);
-    hipLaunchKernelGGL(wf_init, dim3(1), dim3(1), 0, stream, W.ctrl, (int)n0);
-    for (int L = 0; L <= D; L++) {
-        P.level = L;
-        unsigned g_rays = L == 0 ? (unsigned)((n0 + RTC_BLOCK - 1) / RTC_BLOCK) : fixed;
-        long long shadow_items = n0 * (S.n_lights + 1);
-        unsigned g_shadow = L == 0 ? (unsigned)std::min<long long>((shadow_items + RTC_BLOCK - 1) / RTC_BLOCK, 1 << 20) : fixed;
-        if (L > 0) hipLaunchKernelGGL(rtc::wf_clamp, dim3(1), dim3(1), 0, stream, W.ctrl, L, W.cap);
-        hipLaunchKernelGGL((rtc::wf_trace<R, PROF>), dim3(g_rays), block, 0, stream, S, cam, P);
-        if (S.n_tnodes > 0) hipLaunchKernelGGL((rtc::wf_trace_tri<R, PROF>), dim3(g_rays), block, 0, stream, S, P);
-        hipLaunchKernelGGL((rtc::wf_shadow<R, PROF>), dim3(g_shadow), block, 0, stream, S, P);
-        if (S.n_tnodes > 0) hipLaunchKernelGGL((rtc::wf_shadow_tri<R, PROF>), dim3(g_shadow), block, 0, stream, S, P);
-        hipLaunchKernelGGL((rtc::wf_shade<R, PROF>), dim3(g_rays), block, 0, stream, S, P);
-    }
-    for (int L = D - 1; L >= 0; L--) {
-        P.level = L;
-        unsigned g = L == 0 ? (unsigned)((n0 + RTC_BLOCK - 1) / RTC_BLOCK) : fixed;
-        hipLaunchKernelGGL((rtc::wf_reduce<R>), dim3(g), block, 0, stream, P);
-    }
-    P.level = 0;
-    hipLaunchKernelGGL((rtc::wf_output<R>), dim3((unsigned)((n0 + RTC_BLOCK - 1) / RTC_BLOCK)), block, 0, stream, P, cam.hsize, cam.vsize);
-    HIP_TRY(hipGetLastError());
-    return 0;
-}
-
 int launch(rtc_scene* scene, const rtc_camera* cam, const rtc_render_opts* opts, int32_t n_tiles, const int32_t* tile_ids_dev,
            double* rgb_dev, int32_t* hit_id_dev, int64_t* rays_dev, int64_t* work_dev, hipStream_t stream) {
     int T, precision, depth;
@@ -541,21 +470,6 @@ int launch(rtc_scene* scene, const rtc_camera* cam, const rtc_render_opts* opts,
     const long long n_units = blocks * (RTC_BLOCK / 64);
     if (n_units > 0x7FFFFFFFLL) return fail(RTC_ERR_LIMIT, "too many blocks");
     F.n_units = (int32_t)n_units;
-    const bool wavefront = opts && (opts->flags & RTC_FLAG_WAVEFRONT);
-    if (wavefront) {
-        std::lock_guard<std::mutex> lock(scene->ws_mutex);
-        long long cap = (long long)(work * scene->ws_factor) + 4096;
-        if (cap > 0x7FFFFF00LL) cap = 0x7FFFFF00LL;
-        if (cap < work) return fail(RTC_ERR_LIMIT, "frame too large for the wavefront ray pool");
-        if (precision == 64) {
-            if (int rc = ensure_workspace(scene->ws64, scene->ws_mem64, scene->ws_lights64, cap, scene->d64.n_lights, scene->mask_words)) return rc;
-            if (work_dev) return run_wavefront<double, true>(scene->d64, make_camera<double>(*cam), scene->ws64, F, eps, eps_rel, work, stream);
-            return run_wavefront<double, false>(scene->d64, make_camera<double>(*cam), scene->ws64, F, eps, eps_rel, work, stream);
-        }
-        if (int rc = ensure_workspace(scene->ws32, scene->ws_mem32, scene->ws_lights32, cap, scene->d32.n_lights, scene->mask_words)) return rc;
-        if (work_dev) return run_wavefront<float, true>(scene->d32, make_camera<float>(*cam), scene->ws32, F, (float)eps, (float)eps_rel, work, stream);
-        return run_wavefront<float, false>(scene->d32, make_camera<float>(*cam), scene->ws32, F, (float)eps, (float)eps_rel, work, stream);
-    }
     dim3 block(RTC_BLOCK);
     const bool csg = scene->has_csg;
     const bool feedback = !(opts && (opts->flags & RTC_FLAG_NO_FEEDBACK));
@@ -583,13 +497,13 @@ int launch(rtc_scene* scene, const rtc_camera* cam, const rtc_render_opts* opts,
         if (resort) F.cost = scene->fb_cost;
         if (scene->fb_valid) F.order = scene->fb_order[scene->fb_cur];
     }
-    // the level pipeline wherever there are secondary rays to spread out; the single kernel otherwise
-    const bool levels = scene->has_secondary && depth > 0 && !(opts && (opts->flags & RTC_FLAG_SINGLE_KERNEL));
+    const bool levels = scene->has_secondary && depth > 0 && opts && (opts->flags & RTC_FLAG_WAVEFRONT);
     if (levels) {
         const long long n_work = blocks * RTC_BLOCK;
         long long cap = 3 * n_work + 65536;
         if (cap > 0x1FFFFFFFLL) cap = 0x1FFFFFFFLL;
-        if (scene->lv_cap < cap || scene->lv_work < n_work) {
+        if (const char* e = getenv("RTC_LEVEL_POOL")) { long long v = atoll(e); if (v >= 64 && v < cap) cap = v; }   // tests: force the pool-full path
+        if (scene->lv_cap != cap || scene->lv_work < n_work) {
             scene->lv_mem.release(); scene->lv_mem.bytes = 0; scene->lv_cap = 0; scene->lv_work = 0;
             void* p = nullptr;
 #define LV_ALLOC(field, type, count) do { size_t sz_ = (size_t)(count) * sizeof(type); HIP_TRY(hipMalloc(&p, sz_)); scene->lv_mem.ptrs.push_back(p); scene->lv_mem.bytes += sz_; scene->field = static_cast<decltype(scene->field)>(p); } while (0)
@@ -738,7 +652,7 @@ void rtc_scene_destroy(rtc_scene* scene) {
     if (!scene) return;
     (void)hipSetDevice(scene->device);
     scene->shared.release(); scene->mem64.release(); scene->mem32.release();
-    scene->ws_mem64.release(); scene->ws_mem32.release(); scene->fb_mem.release(); scene->lv_mem.release();
+    scene->fb_mem.release(); scene->lv_mem.release();
     delete scene;
 }
 

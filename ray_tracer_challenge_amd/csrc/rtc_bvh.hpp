@@ -35,7 +35,7 @@ struct Bvh {
 
 class BvhBuilder {
 public:
-    static const int32_t EMPTY = INT32_MIN;
+    static constexpr int32_t EMPTY = INT32_MIN;
     BvhBuilder(const std::vector<Aabb>& boxes, int max_leaf, bool median_only)
         : b_(boxes), max_leaf_(max_leaf), median_(median_only) {}
 

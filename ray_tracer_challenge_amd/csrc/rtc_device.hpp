@@ -980,4 +980,49 @@ template <class R> __device__ __forceinline__ Ray<R> ray_for_pixel(const DCamera
     return r;
 }
 
+// block-level reduction of the ray / work counters, then a few atomics per block
+template <bool PROF, bool CSG>
+__device__ __forceinline__ void flush_counters(Counters<PROF, CSG>& cnt, const DFrame& F, unsigned int* red /* LDS, >= 4 * RTC_BLOCK/64 */) {
+    if (F.rays) {
+        __syncthreads();
+        for (int k = 0; k < 4; k++) {
+            unsigned int v = cnt.c[k];
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+            if ((threadIdx.x & 63) == 0) red[k * (RTC_BLOCK / 64) + (threadIdx.x >> 6)] = v;
+        }
+        __syncthreads();
+        if (threadIdx.x < 4) {
+            unsigned long long s = 0;
+            for (int q = 0; q < RTC_BLOCK / 64; q++) s += red[threadIdx.x * (RTC_BLOCK / 64) + q];
+            if (s) atomicAdd(F.rays + threadIdx.x, s);
+        }
+    }
+    if (PROF && F.work) {
+        for (int k = 0; k < W_COUNT; k++) {
+            unsigned int v = cnt.w[k];
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+            if ((threadIdx.x & 63) == 0 && v) atomicAdd(F.work + k, (unsigned long long)v);
+        }
+    }
+}
+template <bool PROF, bool CSG> __device__ __forceinline__ void zero_counters(Counters<PROF, CSG>& cnt) {
+    for (int k = 0; k < 4; k++) cnt.c[k] = 0;
+    for (int k = 0; k < (PROF ? W_COUNT : 1); k++) cnt.w[k] = 0;
+}
+
+// pixel of work item w of the frame (tile order: one wave = one 8x8 block of a T x T tile)
+__device__ __forceinline__ bool work_pixel(const DFrame& F, int hsize, int vsize, long long w, int& x, int& y, size_t& out_index) {
+    const int T = F.tile_size, per_tile = T * T, sub = T / 8;
+    int slot = (int)(w / per_tile), within = (int)(w % per_tile);
+    if (slot >= F.n_tiles) return false;
+    int tile = F.tile_ids ? F.tile_ids[slot] : slot;
+    int tx0 = (tile % F.tiles_x) * T, ty0 = (tile / F.tiles_x) * T;
+    int sb = within >> 6, l = within & 63;
+    x = tx0 + (sb % sub) * 8 + (l & 7);
+    y = ty0 + (sb / sub) * 8 + (l >> 3);
+    if (x >= hsize || y >= vsize) return false;
+    out_index = F.tile_ids ? (size_t)slot * per_tile + (size_t)(y - ty0) * T + (x - tx0) : (size_t)x * vsize + y;
+    return true;
+}
+
 }  // namespace rtc

@@ -17,7 +17,7 @@
 // order in which a pixel's contributions are added differs (a tree instead of a running sum).
 // A full pool is not an error: a ray that finds no room walks its subtree in-lane (trace_tree).
 #pragma once
-#include "rtc_wavefront.hpp"
+#include "rtc_device.hpp"
 
 #define RTC_LV_MAX_LEVELS 8
 
@@ -105,7 +105,7 @@ __global__ __launch_bounds__(RTC_BLOCK, (CSG ? 2 : sizeof(R) == 8 ? RTC_WAVES_F6
         int x, y;
         size_t o;
         int32_t kids = -1;
-        if (wf_pixel(F, cam.hsize, cam.vsize, w, x, y, o)) {
+        if (work_pixel(F, cam.hsize, cam.vsize, w, x, y, o)) {
             Ray<R> ray = ray_for_pixel(cam, x, y);
             cnt.c[0] = 1;
             const uint32_t pixel = (uint32_t)(y * cam.hsize + x);
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(RTC_BLOCK, (CSG ? 2 : sizeof(R) == 8 ? RTC_WAVES_F6
         if (i < n_work) {
             if (Q.kids0[i] != RTC_LV_REDO) continue;
             int x, y; size_t o;
-            if (!wf_pixel(F, cam.hsize, cam.vsize, i, x, y, o)) continue;
+            if (!work_pixel(F, cam.hsize, cam.vsize, i, x, y, o)) continue;
             V3<R> c = trace_tree(S, ray_for_pixel(cam, x, y), mk<R>(1, 1, 1), F.max_depth, 1u, shade_eps, shade_eps_rel, stack, cnt, F.seed,
                                  (uint32_t)(y * cam.hsize + x), leaf);
             F.rgb[3 * o] = (double)c.x; F.rgb[3 * o + 1] = (double)c.y; F.rgb[3 * o + 2] = (double)c.z;
@@ -205,7 +205,7 @@ __global__ __launch_bounds__(RTC_BLOCK) void lv_gather(DFrame F, int hsize, int 
     if (k0 < 0) return;
     int x, y;
     size_t o;
-    if (!wf_pixel(F, hsize, vsize, w, x, y, o)) return;
+    if (!work_pixel(F, hsize, vsize, w, x, y, o)) return;
     double acc[RTC_LV_MAX_LEVELS][3];
     int32_t kid[RTC_LV_MAX_LEVELS], next[RTC_LV_MAX_LEVELS], stage[RTC_LV_MAX_LEVELS];
     int d = 0;

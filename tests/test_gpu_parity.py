@@ -236,7 +236,7 @@ def test_nested_and_blended_patterns_and_nested_csg(oracle_cls):
 @pytest.mark.parametrize("name,size", [("cover", None), ("csg_test", (160, 160)), ("shadow_glamour_shot_nojitter", (120, 48)),
                                        ("teapot", None), ("dragons", (480, 192))])
 def test_wavefront_pipeline_matches_single_kernel(name, size, scenes):
-    """RTC_FLAG_WAVEFRONT (rays in HBM queues, one sweep of kernels per bounce level) traces the same rays."""
+    """RTC_FLAG_WAVEFRONT (the level pipeline: one kernel per bounce level over a ray pool) traces the same rays."""
     cam, world, sc = scenes(name)
     if size:
         cam = cam.resized(*size)
@@ -275,3 +275,20 @@ def test_launch_order_feedback_changes_nothing(name, size, scenes):
     a, _ = sc.render(cam2, precision="fp64", feedback=False)
     b, _ = sc.render(cam2, precision="fp64")
     np.testing.assert_array_equal(a, b)
+
+
+def test_level_pipeline_full_pool_is_still_exact(scenes, monkeypatch):
+    """When the ray pool of the level pipeline is full, the rays that found no room are traced in-lane afterwards
+    (lv_redo): same image, same ray counts."""
+    cam, world, sc = scenes("cover")
+    s1, s2, s3 = {}, {}, {}
+    a, ia = sc.render(cam, precision="fp64", want_ids=True, stats=s1)
+    b, ib = sc.render(cam, precision="fp64", want_ids=True, stats=s2, wavefront=True)
+    monkeypatch.setenv("RTC_LEVEL_POOL", "700")          # far fewer than the secondary rays of the frame
+    c, ic = sc.render(cam, precision="fp64", want_ids=True, stats=s3, wavefront=True)
+    monkeypatch.delenv("RTC_LEVEL_POOL")
+    assert sum(s1["rays"][2:]) > 700
+    np.testing.assert_allclose(a, b, rtol=0, atol=1e-9)
+    np.testing.assert_allclose(a, c, rtol=0, atol=1e-9)
+    np.testing.assert_array_equal(ia, ic)
+    assert s1["rays"] == s2["rays"] == s3["rays"]
