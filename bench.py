@@ -92,12 +92,12 @@ def main():
     rays_dev = torch.zeros(12, dtype=torch.int64, device=dev)
     frame = fg.frame
 
-    def step(precision, count_work=False):
+    def step(precision, count_work=False, feedback=True):
         stream = torch.cuda.current_stream().cuda_stream
         if world == 1:
             # whole frame straight into the canvas layout: no tile list, no gather
             scene.render_device(cam, frame.data_ptr(), rays_ptr=rays_dev.data_ptr(), precision=precision,
-                                max_depth=args.depth, tile_size=T, stream=stream, count_work=count_work)
+                                max_depth=args.depth, tile_size=T, stream=stream, count_work=count_work, feedback=feedback)
             return
         render_distributed(scene, cam, fg, precision, args.depth, rays_dev.data_ptr(), stream, count_work)
 
@@ -107,16 +107,16 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    def timed(precision, steps, warmup):
+    def timed(precision, steps, warmup, feedback=True):
         for _ in range(warmup):
-            step(precision)
+            step(precision, feedback=feedback)
         sync()
         rays_dev.zero_()
         torch.cuda.synchronize()
         sync()
         t0 = time.perf_counter()
         for _ in range(steps):
-            step(precision)
+            step(precision, feedback=feedback)
         sync()
         dt = time.perf_counter() - t0
         dt_t = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -154,6 +154,11 @@ def main():
     work = [int(v) for v in rays_dev[4:12].tolist()]
     dt32, rays32 = timed("fp32", args.steps, args.warmup)
     kms32 = kernel_only("fp32", max(3, min(args.steps, 10)))
+    # for the record: the same frames launched in plain tile order (no cost feedback from the previous frame)
+    plain = None
+    if world == 1:
+        dtp, _ = timed("fp64", max(3, args.steps // 2), 1, feedback=False)
+        plain = dtp / max(3, args.steps // 2) * 1e3
 
     if rank == 0:
         flops = algorithmic_flops(work)
@@ -175,6 +180,8 @@ def main():
             "rays_per_frame": {"primary": rays[0] // args.steps, "shadow": rays[1] // args.steps,
                                "reflection": rays[2] // args.steps, "refraction": rays[3] // args.steps},
             "ms_per_frame": round(dt / args.steps * 1e3, 4),
+            "launch_order": {"policy": "dearest 8x8 blocks first, from the wave costs the first two frames of a view record",
+                             "ms_per_frame_plain_tile_order": None if plain is None else round(plain, 4)},
             "fp32": {"value": round(sum(rays32) / dt32 / 1e6, 3), "unit": "Mrays/s", "ms_per_frame": round(dt32 / args.steps * 1e3, 4),
                      "kernel_ms": round(kms32, 4)},
             "roofline": {"bound": "valu", "achieved": round(achieved, 4), "peak": PEAK_TFLOPS["fp64"], "unit": "TFLOP/s",

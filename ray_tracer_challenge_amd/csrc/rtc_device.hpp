@@ -366,8 +366,14 @@ __device__ __forceinline__ bool traverse_bvh(const DScene<R>& S, const Ray<R>& r
     // absolute) on the host, which covers rounding the ray to fp32, and the slab distances get a
     // 1e-5 relative slack before every comparison -- the test can only accept MORE than an exact
     // one would, never less, so no leaf the leaf test would accept is culled.
-    const float ox = (float)ray.o.x, oy = (float)ray.o.y, oz = (float)ray.o.z;
-    const float ix = 1.0f / (float)ray.d.x, iy = 1.0f / (float)ray.d.y, iz = 1.0f / (float)ray.d.z;
+    // slab distance (b - o) / d as one fused multiply-add b * (1/d) + (-o/d); a direction component of 0
+    // gets a huge finite reciprocal instead of inf, so that no 0 * inf appears (the sign of b - o then
+    // decides, as it should, and the outward padding covers an origin that sits on the slab plane)
+    float ix = 1.0f / (float)ray.d.x, iy = 1.0f / (float)ray.d.y, iz = 1.0f / (float)ray.d.z;
+    if (!(fabsf(ix) <= 1e30f)) ix = copysignf(1e30f, (float)ray.d.x);
+    if (!(fabsf(iy) <= 1e30f)) iy = copysignf(1e30f, (float)ray.d.y);
+    if (!(fabsf(iz) <= 1e30f)) iz = copysignf(1e30f, (float)ray.d.z);
+    const float ox = -(float)ray.o.x * ix, oy = -(float)ray.o.y * iy, oz = -(float)ray.o.z * iz;
     const float tlo32 = (float)tlo;
     int sp = 0;
     int node = 0;
@@ -385,10 +391,9 @@ __device__ __forceinline__ bool traverse_bvh(const DScene<R>& S, const Ray<R>& r
 #pragma unroll
             for (int k = 0; k < 2; k++) {
                 const float* lo = b + 6 * k; const float* hi = lo + 3;
-                float x0 = (lo[0] - ox) * ix, x1 = (hi[0] - ox) * ix;
-                float y0 = (lo[1] - oy) * iy, y1 = (hi[1] - oy) * iy;
-                float z0 = (lo[2] - oz) * iz, z1 = (hi[2] - oz) * iz;
-                // fmin/fmax drop the NaN of 0*inf (origin on a slab plane of a parallel ray): conservative
+                float x0 = fmaf(lo[0], ix, ox), x1 = fmaf(hi[0], ix, ox);
+                float y0 = fmaf(lo[1], iy, oy), y1 = fmaf(hi[1], iy, oy);
+                float z0 = fmaf(lo[2], iz, oz), z1 = fmaf(hi[2], iz, oz);
                 float n = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
                 float f = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
                 near[k] = n - fabsf(n) * 1e-5f;
