@@ -13,6 +13,12 @@ c = sqlite3.connect(os.path.join(src, "kt", "kt_results.db"))
 lines.append("%-110s %6s %14s %12s %7s" % ("kernel", "calls", "total_us", "avg_us", "%"))
 for name, calls, total, avg, pct in c.execute("select name,total_calls,total_duration,average,percentage from top_kernels"):
     lines.append("%-110s %6d %14.3f %12.3f %7.2f" % (name[:110], calls, total, avg, pct))
+rows = [(e - b) / 1000.0 for b, e in c.execute("select start, end from kernels where name like '%trace_kernel<double, false%' order by start")]
+if rows:
+    import statistics
+    lines += ["", "trace_kernel<double, false, *> per launch, in launch order (us): the first two frames of a view run in plain tile order and",
+              "record wave costs, the last launches are bench.py's plain-order comparison; the median is the steady state bench.py times:",
+              " ".join("%.0f" % r for r in rows), "median %.1f us" % statistics.median(rows)]
 with open(os.path.join(src, "bench_under_rocprof.json")) as f:
     lines += ["", "bench.py JSON line of the same run:", f.read().strip()]
 open(os.path.join("profiles", tag + "_kernel_trace_stats.txt"), "w").write("\n".join(lines) + "\n")
