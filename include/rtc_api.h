@@ -204,7 +204,9 @@ int rtc_render_tiles(rtc_scene *scene, const rtc_camera *cam, const rtc_render_o
  * tile_ids_dev == NULL renders the whole frame into the [x][y][c] layout; otherwise the
  * compact tile layout above.  rays_dev (may be NULL) is ADDED to: [4] int64 ray counts, or [12]
  * with RTC_FLAG_COUNT_WORK ([4..11] = the work counters of rtc_stats).  Asynchronous on
- * `stream` (a hipStream_t, NULL = default stream). */
+ * `stream` (a hipStream_t, NULL = default stream).  Render calls on one scene handle must be
+ * stream-ordered (same stream, or synchronised by the caller): the handle owns the launch-order
+ * buffers of RTC_FLAG_NO_FEEDBACK's comment and the ray pool of RTC_FLAG_WAVEFRONT. */
 int rtc_render_device(rtc_scene *scene, const rtc_camera *cam, const rtc_render_opts *opts,
                       int32_t n_tiles, const int32_t *tile_ids_dev,
                       double *rgb_dev, int32_t *hit_id_dev, int64_t *rays_dev, void *stream);
