@@ -292,3 +292,27 @@ def test_level_pipeline_full_pool_is_still_exact(scenes, monkeypatch):
     np.testing.assert_allclose(a, c, rtol=0, atol=1e-9)
     np.testing.assert_array_equal(ia, ic)
     assert s1["rays"] == s2["rays"] == s3["rays"]
+
+
+def test_jittered_area_light(scenes):
+    """shadow_glamour_shot.yml as shipped (jitter: true).  The reference draws from Python's global RNG in a
+    process-timing-dependent order, so there is no image to compare with; the kernel's counter-based samples must be
+    reproducible for a seed, differ between seeds, leave every pixel whose light cells are all lit or all shadowed in
+    the unjittered frame (nearly) alone, and average out to the unjittered penumbra."""
+    cam, _, sj = scenes("shadow_glamour_shot")
+    _, _, sn = scenes("shadow_glamour_shot_nojitter")
+    cam = cam.resized(240, 96)
+    plain, ids_plain = sn.render(cam, precision="fp64", want_ids=True)
+    a, ids_a = sj.render(cam, precision="fp64", want_ids=True, seed=1)
+    b, _ = sj.render(cam, precision="fp64", seed=1)
+    c, _ = sj.render(cam, precision="fp64", seed=2)
+    lv, _ = sj.render(cam, precision="fp64", seed=1, wavefront=True)
+    np.testing.assert_array_equal(a, b)
+    np.testing.assert_allclose(a, lv, rtol=0, atol=1e-9)
+    np.testing.assert_array_equal(ids_a, ids_plain)
+    assert np.abs(a - c).max() > 1e-3
+    mean = np.mean([sj.render(cam, precision="fp64", seed=s)[0] for s in range(3, 19)], axis=0)
+    assert np.abs(a - plain).mean() < 0.01
+    # averaging 16 seeds removes most of the noise; what stays is the bias of cell centres against uniform samples
+    assert np.abs(mean - plain).mean() < 0.75 * np.abs(a - plain).mean()
+    assert (np.abs(a - plain).max(axis=2) > 0.05).mean() < 0.2                # the penumbra is a minority of the frame
