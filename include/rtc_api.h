@@ -217,6 +217,14 @@ int rtc_render_device(rtc_scene *scene, const rtc_camera *cam, const rtc_render_
 int rtc_quantize_device(const double *rgb_dev, int32_t hsize, int32_t vsize, double max_component,
                         uint8_t *out_dev, void *stream);
 
+/* The canvas from compact tiles (renderer.py:819-829 collects the pool's tiles into the shared
+ * canvas, canvas.py:60-61): slot k of tiles_dev ([n_slots][tile_size][tile_size][3] doubles, the
+ * layout rtc_render_device writes with a tile list) goes to tile tile_ids_dev[k] of the
+ * [x][y][c] frame; slots with a negative tile id (padding of a gathered buffer) and pixels
+ * outside the image are skipped.  Device pointers; asynchronous on `stream`. */
+int rtc_scatter_tiles_device(const double *tiles_dev, const int32_t *tile_ids_dev, int32_t n_slots, int32_t tile_size,
+                             int32_t hsize, int32_t vsize, double *frame_dev, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

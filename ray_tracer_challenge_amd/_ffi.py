@@ -57,7 +57,8 @@ class SceneInfo(C.Structure):
 
 
 EXPORTS = ["rtc_version", "rtc_device_count", "rtc_last_error", "rtc_scene_create", "rtc_scene_destroy",
-           "rtc_scene_get_info", "rtc_render", "rtc_render_tiles", "rtc_render_device", "rtc_quantize_device"]
+           "rtc_scene_get_info", "rtc_render", "rtc_render_tiles", "rtc_render_device", "rtc_quantize_device",
+           "rtc_scatter_tiles_device"]
 
 
 class RtcError(RuntimeError):
@@ -103,6 +104,7 @@ def lib():
                                        C.POINTER(Stats)]
         L.rtc_render_device.argtypes = [_P, C.POINTER(CameraDesc), C.POINTER(RenderOpts), C.c_int32, _P, _P, _P, _P, _P]
         L.rtc_quantize_device.argtypes = [_P, C.c_int32, C.c_int32, C.c_double, _P, _P]
+        L.rtc_scatter_tiles_device.argtypes = [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P]
         _lib = L
     return _lib
 
@@ -208,6 +210,12 @@ class Scene(object):
         c, o = make_camera(cam), make_opts(precision, max_depth, tile_size, shade_eps, seed, count_work, wavefront=wavefront, feedback=feedback)
         _check(lib().rtc_render_device(self.handle, C.byref(c), C.byref(o), int(n_tiles), _P(tile_ids_ptr or None),
                                        _P(rgb_ptr), _P(ids_ptr or None), _P(rays_ptr or None), _P(stream or None)))
+
+
+def scatter_tiles_device(tiles_ptr, tile_ids_ptr, n_slots, tile_size, hsize, vsize, frame_ptr, stream=None):
+    """Compact tiles in HBM -> the [x][y][c] canvas in HBM (device pointers as ints)."""
+    _check(lib().rtc_scatter_tiles_device(_P(tiles_ptr), _P(tile_ids_ptr), int(n_slots), int(tile_size), int(hsize), int(vsize),
+                                          _P(frame_ptr), _P(stream or None)))
 
 
 def _fill_stats(stats, st):

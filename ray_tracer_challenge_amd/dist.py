@@ -44,37 +44,54 @@ def unpermute_index(hsize, vsize, world, tile=TILE):
 
 
 class FrameGather(object):
-    """Preallocated buffers + index tables for gathering one frame per call to rank 0."""
+    """Preallocated buffers + tile tables for gathering one frame per call to rank 0.
+
+    On a GPU the un-permute is one HIP kernel (`rtc_scatter_tiles_device`) over the gathered buffer, which
+    is a single allocation whose per-rank slices the collective receives into; on the CPU (gloo tests)
+    it is a torch index copy with the same tile tables."""
 
     def __init__(self, hsize, vsize, world, rank, device, tile=TILE, group=None):
         import torch
         self.torch = torch
         self.hsize, self.vsize, self.world, self.rank, self.tile, self.group = hsize, vsize, world, rank, tile, group
         self.mine = rank_tiles(hsize, vsize, world, rank, tile)
-        per = slots_per_rank(hsize, vsize, world, tile)
-        self.compact = torch.zeros((per, tile, tile, 3), dtype=torch.float64, device=device)
+        self.per = per = slots_per_rank(hsize, vsize, world, tile)
+        self.on_gpu = torch.device(device).type == "cuda"
         self.tiles_dev = torch.from_numpy(self.mine.copy()).to(device)
         self.frame = None
         self.gathered = None
         if rank == 0:
             self.frame = torch.zeros((hsize, vsize, 3), dtype=torch.float64, device=device)
-            src, dst = unpermute_index(hsize, vsize, world, tile)
-            self.src, self.dst = torch.from_numpy(src).to(device), torch.from_numpy(dst).to(device)
-            if world > 1:
-                self.gathered = [torch.zeros_like(self.compact) for _ in range(world)]
+            # every rank's slots back to back: the collective receives straight into the slices
+            self.all_tiles = torch.zeros((world, per, tile, tile, 3), dtype=torch.float64, device=device)
+            self.compact = self.all_tiles[0] if world == 1 else torch.zeros((per, tile, tile, 3), dtype=torch.float64, device=device)
+            self.gathered = [self.all_tiles[r] for r in range(world)]
+            slots = np.full((world, per), -1, np.int32)
+            for r in range(world):
+                t = rank_tiles(hsize, vsize, world, r, tile)
+                slots[r, :len(t)] = t
+            self.slot_tiles = torch.from_numpy(slots.ravel().copy()).to(device)
+            if not self.on_gpu:
+                src, dst = unpermute_index(hsize, vsize, world, tile)
+                self.src, self.dst = torch.from_numpy(src), torch.from_numpy(dst)
+        else:
+            self.compact = torch.zeros((per, tile, tile, 3), dtype=torch.float64, device=device)
 
     def gather(self):
         """After this rank's tiles are in `self.compact`: returns the canvas tensor on rank 0, None elsewhere."""
         torch = self.torch
         if self.world > 1:
             import torch.distributed as dist
-            dist.gather(self.compact, self.gathered, dst=0, group=self.group)
+            dist.gather(self.compact, self.gathered if self.rank == 0 else None, dst=0, group=self.group)
             if self.rank != 0:
                 return None
-            flat = torch.cat([g.reshape(-1, 3) for g in self.gathered], dim=0)
+        if self.on_gpu:
+            from . import _ffi
+            _ffi.scatter_tiles_device(self.all_tiles.data_ptr(), self.slot_tiles.data_ptr(), self.world * self.per, self.tile,
+                                      self.hsize, self.vsize, self.frame.data_ptr(), torch.cuda.current_stream().cuda_stream)
         else:
-            flat = self.compact.reshape(-1, 3)
-        self.frame.view(-1, 3).index_copy_(0, self.dst, flat.index_select(0, self.src))
+            flat = self.all_tiles.reshape(-1, 3)
+            self.frame.view(-1, 3).index_copy_(0, self.dst, flat.index_select(0, self.src))
         return self.frame
 
 

@@ -316,3 +316,26 @@ def test_jittered_area_light(scenes):
     # averaging 16 seeds removes most of the noise; what stays is the bias of cell centres against uniform samples
     assert np.abs(mean - plain).mean() < 0.75 * np.abs(a - plain).mean()
     assert (np.abs(a - plain).max(axis=2) > 0.05).mean() < 0.2                # the penumbra is a minority of the frame
+
+
+def test_tiles_to_canvas_on_device(scenes):
+    """The multi-GPU frame assembly on one GPU: two "ranks" trace interleaved tile lists into compact buffers, the
+    buffers sit back to back like a gathered one (with padding slots), rtc_scatter_tiles_device builds the canvas."""
+    import torch
+    from ray_tracer_challenge_amd import dist
+    cam, world, sc = scenes("cover")
+    cam = cam.resized(150, 70)                                   # ragged: 5 x 3 tiles of 32, the last ones partial
+    want, _ = sc.render(cam, precision="fp64")
+    dev = torch.device("cuda", 0)
+    fgs = [dist.FrameGather(cam.hsize, cam.vsize, 2, r, dev) for r in range(2)]
+    stream = torch.cuda.current_stream().cuda_stream
+    for fg in fgs:
+        sc.render_device(cam, fg.compact.data_ptr(), tile_ids_ptr=fg.tiles_dev.data_ptr(), n_tiles=len(fg.mine), tile_size=fg.tile, stream=stream)
+    root = fgs[0]
+    for r, fg in enumerate(fgs):
+        root.all_tiles[r].copy_(fg.compact)                      # what the RCCL gather does
+    _ffi.scatter_tiles_device(root.all_tiles.data_ptr(), root.slot_tiles.data_ptr(), 2 * root.per, root.tile, cam.hsize, cam.vsize,
+                              root.frame.data_ptr(), stream)
+    got = root.frame
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(got.cpu().numpy(), want)
