@@ -47,10 +47,11 @@ __global__ __launch_bounds__(RTC_BLOCK, (CSG ? 2 : sizeof(R) == 8 ? RTC_WAVES_F6
     rtc::Counters<PROF, CSG> cnt;
     rtc::zero_counters(cnt);
     const long long t_start = F.cost ? (long long)wall_clock64() : 0;
-    const long long unit = rtc::wave_unit(F);
+    bool lane_on;
+    const long long unit = rtc::wave_unit(F, lane_on);
     int x, y;
     size_t o;
-    if (unit >= 0 && rtc::work_pixel(F, cam.hsize, cam.vsize, unit * 64 + lane, x, y, o)) {
+    if (unit >= 0 && lane_on && rtc::work_pixel(F, cam.hsize, cam.vsize, unit * 64 + lane, x, y, o)) {
         rtc::Ray<R> ray = rtc::ray_for_pixel(cam, x, y);
         cnt.c[0] = 1;
         int hit_leaf;
@@ -67,15 +68,20 @@ __global__ __launch_bounds__(RTC_BLOCK, (CSG ? 2 : sizeof(R) == 8 ? RTC_WAVES_F6
     }
     if (F.cost && unit >= 0 && lane == 0) {
         long long dt = (long long)wall_clock64() - t_start;
-        F.cost[unit] = (uint32_t)(dt < 0 ? 0 : dt > 0x7FFFFFFFLL ? 0x7FFFFFFFLL : dt);
+        atomicAdd(F.cost + unit, (uint32_t)(dt < 0 ? 0 : dt > 0x0FFFFFFFLL ? 0x0FFFFFFFLL : dt));
     }
     rtc::flush_counters(cnt, F, reinterpret_cast<unsigned int*>(s_stack));
 }
 
-// Next frame's launch order from this frame's unit costs (one block; n is a few 10^4): units in
+// Next frame's launch order from this frame's unit costs (one block; n is a few 10^4): entries in
 // descending cost by buckets of a quarter octave -- the launch cannot end before its longest wave
-// does, so the long ones go first.  The order inside a bucket is whatever the atomics give; any
-// order renders the same image.
+// does, so the long ones go first.  And when the GPU has more wave slots than work (a rank's share
+// of a frame on many GPUs) the longest wave IS the launch: units whose cost is several times the
+// even share of a slot (total cost / n_slots) are split into four 4x4 quadrant waves (cost >=
+// split4 x share) or sixteen 2x2 waves (>= split16 x share), dearest buckets first, as far as the
+// spare entries go.  A split wave is shorter, not proportionally (measured: about 0.65x for a
+// quadrant), so nothing is split while the GPU is full.  The order inside a bucket is whatever the
+// atomics give; any order and any split render the same image.
 #define RTC_ORDER_BUCKETS 128
 __device__ __forceinline__ int order_bucket(uint32_t c) {
     int lg = 31 - __clz((int)(c | 1u));                              // floor(log2 c)
@@ -83,18 +89,60 @@ __device__ __forceinline__ int order_bucket(uint32_t c) {
     int b = 4 * lg + frac;
     return RTC_ORDER_BUCKETS - 1 - (b > RTC_ORDER_BUCKETS - 1 ? RTC_ORDER_BUCKETS - 1 : b);   // dearest first
 }
-__global__ __launch_bounds__(1024) void order_kernel(const uint32_t* cost, int32_t* order, int n) {
+__device__ __forceinline__ double order_bucket_floor(int bucket) {     // smallest cost that lands in the bucket
+    int j = RTC_ORDER_BUCKETS - 1 - bucket, lg = j >> 2, frac = j & 3;
+    return lg >= 2 ? (double)(4 + frac) * (double)(1ULL << (lg - 2)) : (double)(1ULL << lg);
+}
+__global__ __launch_bounds__(1024) void order_kernel(const uint32_t* cost, int32_t* order, int n, int n_entries, int n_slots, float split4,
+                                                     float split16, int32_t* used) {
     __shared__ unsigned int hist[RTC_ORDER_BUCKETS], cursor[RTC_ORDER_BUCKETS];
+    __shared__ unsigned char ways[RTC_ORDER_BUCKETS];     // 1, 4 or 16 waves for the units of the bucket
+    __shared__ unsigned long long total;
+    for (int b = threadIdx.x; b < RTC_ORDER_BUCKETS; b += blockDim.x) { hist[b] = 0; ways[b] = 1; }
+    if (threadIdx.x == 0) total = 0;
+    __syncthreads();
+    unsigned long long mine = 0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) { uint32_t c = cost[i]; mine += c; atomicAdd(&hist[order_bucket(c)], 1u); }
+    atomicAdd(&total, mine);
+    __syncthreads();
+    if (threadIdx.x == 0 && split4 > 0.0f) {
+        double share = (double)total / (double)(n_slots > 0 ? n_slots : 1);
+        double from4 = fmax((double)split4 * share, 1000.0), from16 = fmax((double)split16 * share, 4000.0);   // never below 10 / 40 us
+        long long spare = (long long)n_entries - n;
+        for (int b = 0; b < RTC_ORDER_BUCKETS && spare > 0; b++) {            // whole buckets, dearest first, while they fit
+            double floor_cost = order_bucket_floor(b);
+            int k = (split16 > 0.0f && floor_cost >= from16) ? 16 : (floor_cost >= from4 ? 4 : 1);
+            if (k == 1) break;
+            if ((long long)hist[b] * (k - 1) > spare) k = 4;
+            if ((long long)hist[b] * (k - 1) > spare) break;
+            spare -= (long long)hist[b] * (k - 1);
+            ways[b] = (unsigned char)k;
+        }
+    }
+    __syncthreads();
     for (int b = threadIdx.x; b < RTC_ORDER_BUCKETS; b += blockDim.x) hist[b] = 0;
     __syncthreads();
-    for (int i = threadIdx.x; i < n; i += blockDim.x) atomicAdd(&hist[order_bucket(cost[i])], 1u);
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        uint32_t c = cost[i];
+        unsigned int k = ways[order_bucket(c)];
+        atomicAdd(&hist[order_bucket(c / k)], k);
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
         unsigned int run = 0;
         for (int b = 0; b < RTC_ORDER_BUCKETS; b++) { cursor[b] = run; run += hist[b]; }
+        total = run;
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < n; i += blockDim.x) order[atomicAdd(&cursor[order_bucket(cost[i])], 1u)] = i;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        uint32_t c = cost[i];
+        unsigned int k = ways[order_bucket(c)];
+        unsigned int at = atomicAdd(&cursor[order_bucket(c / k)], k);
+        if (k == 1) order[at] = i * 32;
+        else for (unsigned int q = 0; q < k; q++) order[at + q] = i * 32 + (k == 4 ? 1 : 5) + (int)q;
+    }
+    for (int i = (int)total + threadIdx.x; i < n_entries; i += blockDim.x) order[i] = -1;
+    if (threadIdx.x == 0) *used = (int32_t)total;      // the host sizes later grids by it once it has arrived
 }
 
 // canvas.py:133-156
@@ -195,6 +243,8 @@ struct rtc_scene {
     uint32_t* fb_cost = nullptr; int32_t* fb_order[2] = {nullptr, nullptr};
     long long fb_units = 0; int fb_cur = 0; bool fb_valid = false;
     int n_cus = 0;
+    int32_t* fb_used_dev = nullptr; int32_t* fb_used_host = nullptr;   // entries the current order really has (host copy: pinned)
+    hipEvent_t fb_used_event = nullptr; bool fb_used_known = false;
     // what the current order was measured on, and how many frames of it have been sorted: the order
     // is rebuilt after the first two frames of a view (the second one measured under the new order)
     // and then kept until the view changes
@@ -323,6 +373,10 @@ int validate(const rtc_scene_desc& d) {
             return fail(RTC_ERR_INVALID, "area light %d: steps must be >= 1", i);
     return 0;
 }
+
+// split units dearer than these x (total cost / wave slots) into 4 / 16 waves; 0 = never (development overrides: RTC_SPLIT4, RTC_SPLIT16)
+float g_split4 = [] { const char* e = getenv("RTC_SPLIT4"); return e ? (float)atof(e) : 2.0f; }();
+float g_split16 = [] { const char* e = getenv("RTC_SPLIT16"); return e ? (float)atof(e) : 6.0f; }();
 
 int create_impl(const rtc_scene_desc& d, rtc_scene* sc) {
     {
@@ -490,6 +544,9 @@ int launch(rtc_scene* scene, const rtc_camera* cam, const rtc_render_opts* opts,
     const bool feedback = !(opts && (opts->flags & RTC_FLAG_NO_FEEDBACK));
     const int waves_per_simd = csg ? 2 : (precision == 64 ? RTC_WAVES_F64 : RTC_WAVES_F32);
     dim3 grid((unsigned)blocks);
+    // spare launch-order entries for the quadrants of split units (3 more per split unit)
+    const long long n_entries = ((n_units + 3 * (n_units / 4 + 64)) + RTC_BLOCK / 64 - 1) / (RTC_BLOCK / 64) * (RTC_BLOCK / 64);
+    F.n_entries = (int32_t)n_units;
     std::lock_guard<std::mutex> fb_lock(scene->ws_mutex);
     bool resort = false;
     if (scene->fb_units != n_units) {
@@ -497,9 +554,13 @@ int launch(rtc_scene* scene, const rtc_camera* cam, const rtc_render_opts* opts,
         void* p = nullptr;
         HIP_TRY(hipMalloc(&p, (size_t)n_units * sizeof(uint32_t))); scene->fb_mem.ptrs.push_back(p); scene->fb_cost = (uint32_t*)p;
         for (int k = 0; k < 2; k++) {
-            HIP_TRY(hipMalloc(&p, (size_t)n_units * sizeof(int32_t))); scene->fb_mem.ptrs.push_back(p); scene->fb_order[k] = (int32_t*)p;
+            HIP_TRY(hipMalloc(&p, (size_t)n_entries * sizeof(int32_t))); scene->fb_mem.ptrs.push_back(p); scene->fb_order[k] = (int32_t*)p;
         }
-        scene->fb_mem.bytes = (size_t)n_units * 12;
+        HIP_TRY(hipMalloc(&p, sizeof(int32_t))); scene->fb_mem.ptrs.push_back(p); scene->fb_used_dev = (int32_t*)p;
+        if (!scene->fb_used_host) HIP_TRY(hipHostMalloc((void**)&scene->fb_used_host, sizeof(int32_t), hipHostMallocDefault));
+        if (!scene->fb_used_event) HIP_TRY(hipEventCreateWithFlags(&scene->fb_used_event, hipEventDisableTiming));
+        scene->fb_used_known = false;
+        scene->fb_mem.bytes = (size_t)n_units * 4 + (size_t)n_entries * 8;
         scene->fb_units = n_units;
     }
     if (feedback) {
@@ -509,8 +570,20 @@ int launch(rtc_scene* scene, const rtc_camera* cam, const rtc_render_opts* opts,
         if (memcmp(&key, &scene->fb_key, sizeof(key)) != 0) { scene->fb_key = key; scene->fb_age = 0; }
         resort = scene->fb_age < 2;
         scene->fb_age++;
-        if (resort) F.cost = scene->fb_cost;
-        if (scene->fb_valid) F.order = scene->fb_order[scene->fb_cur];
+        if (resort) {
+            HIP_TRY(hipMemsetAsync(scene->fb_cost, 0, (size_t)n_units * sizeof(uint32_t), stream));
+            F.cost = scene->fb_cost;
+        }
+        if (scene->fb_valid) {
+            F.order = scene->fb_order[scene->fb_cur];
+            long long used = n_entries;
+            if (!scene->fb_used_known && scene->fb_used_event && hipEventQuery(scene->fb_used_event) == hipSuccess) scene->fb_used_known = true;
+            if (scene->fb_used_known && *scene->fb_used_host >= n_units && *scene->fb_used_host <= n_entries) used = *scene->fb_used_host;
+            (void)hipGetLastError();       // a not-ready query is not an error
+            used = (used + RTC_BLOCK / 64 - 1) / (RTC_BLOCK / 64) * (RTC_BLOCK / 64);
+            F.n_entries = (int32_t)used;
+            grid = dim3((unsigned)(used / (RTC_BLOCK / 64)));
+        }
     }
     const bool levels = scene->has_secondary && depth > 0 && opts && (opts->flags & RTC_FLAG_WAVEFRONT);
     if (levels) {
@@ -565,7 +638,11 @@ int launch(rtc_scene* scene, const rtc_camera* cam, const rtc_render_opts* opts,
     if (feedback && resort) {
         // this frame's costs -> the order the next frame on this scene launches in (other buffer: the
         // kernel above may still be reading the current one)
-        hipLaunchKernelGGL(order_kernel, dim3(1), dim3(1024), 0, stream, scene->fb_cost, scene->fb_order[1 - scene->fb_cur], (int)n_units);
+        hipLaunchKernelGGL(order_kernel, dim3(1), dim3(1024), 0, stream, scene->fb_cost, scene->fb_order[1 - scene->fb_cur], (int)n_units,
+                           (int)n_entries, scene->n_cus * 4 * waves_per_simd, g_split4, g_split16, scene->fb_used_dev);
+        scene->fb_used_known = false;
+        HIP_TRY(hipMemcpyAsync(scene->fb_used_host, scene->fb_used_dev, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipEventRecord(scene->fb_used_event, stream));
         HIP_TRY(hipGetLastError());
         scene->fb_cur = 1 - scene->fb_cur;
         scene->fb_valid = true;
@@ -668,6 +745,8 @@ void rtc_scene_destroy(rtc_scene* scene) {
     (void)hipSetDevice(scene->device);
     scene->shared.release(); scene->mem64.release(); scene->mem32.release();
     scene->fb_mem.release(); scene->lv_mem.release();
+    if (scene->fb_used_host) (void)hipHostFree(scene->fb_used_host);
+    if (scene->fb_used_event) (void)hipEventDestroy(scene->fb_used_event);
     delete scene;
 }
 

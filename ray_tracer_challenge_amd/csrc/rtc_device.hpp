@@ -149,20 +149,29 @@ struct DFrame {
     double* rgb; int32_t* hit_id; unsigned long long* rays; unsigned long long* work;
     int32_t max_depth;
     uint64_t seed;
-    // Launch order of the pixel kernels: unit = 64 work items = one 8x8 pixel block = one wave's job; the
-    // k-th wave of the grid renders unit order[k] (blocks are dispatched in index order, so the first
-    // entries start first).
-    int32_t n_units;
-    const int32_t* order;        // [n_units] a permutation of the units, or NULL = 0, 1, 2, ...
-    uint32_t* cost;              // [n_units] wall-clock ticks the unit took, or NULL = do not record
+    // Launch order of the pixel kernels: unit = 64 work items = one 8x8 pixel block.  The k-th wave of the
+    // grid renders entry order[k] = unit * 32 + part (workgroups are dispatched in index order, so the first
+    // entries start first): part 0 = the whole block, 1..4 = one 4x4 quadrant of it, 5..20 = one 2x2 piece
+    // (the dearest blocks are spread over 4 or 16 waves when the GPU has slots to spare), -1 = nothing.
+    int32_t n_units, n_entries;
+    const int32_t* order;        // [n_entries], or NULL = units 0, 1, 2, ... whole
+    uint32_t* cost;              // [n_units] wall-clock ticks spent on the unit (parts add up; zeroed by the host), or NULL
 };
 
-// the unit of this wave, -1 if there is none
-__device__ __forceinline__ long long wave_unit(const DFrame& F) {
+// the unit of this wave (-1 if there is none) and which of its lanes take part
+__device__ __forceinline__ long long wave_unit(const DFrame& F, bool& lane_on) {
     long long entry = (long long)blockIdx.x * (RTC_BLOCK / 64) + (threadIdx.x >> 6);
-    if (entry >= F.n_units) return -1;
-    int u = F.order ? F.order[entry] : (int)entry;
-    return (u < 0 || u >= F.n_units) ? -1 : u;
+    lane_on = true;
+    if (!F.order) return entry < F.n_units ? entry : -1;
+    if (entry >= F.n_entries) return -1;
+    int e = F.order[entry];
+    if (e < 0) return -1;
+    int u = e >> 5, part = e & 31;
+    if (u >= F.n_units || part > 20) return -1;
+    const int lx = threadIdx.x & 7, ly = (threadIdx.x >> 3) & 7;
+    if (part >= 5) lane_on = (lx >> 1) == ((part - 5) & 3) && (ly >> 1) == ((part - 5) >> 2);
+    else if (part != 0) lane_on = (((ly >> 2) << 1) | (lx >> 2)) == part - 1;
+    return u;
 }
 
 // c: rays traced (primary, shadow, reflection, refraction).  w (PROF builds only): BVH node

@@ -99,8 +99,9 @@ __global__ __launch_bounds__(RTC_BLOCK, (CSG ? 2 : sizeof(R) == 8 ? RTC_WAVES_F6
     CNT cnt;
     zero_counters(cnt);
     const long long t_start = F.cost ? (long long)wall_clock64() : 0;
-    const long long unit = wave_unit(F);
-    if (unit >= 0) {
+    bool lane_on;
+    const long long unit = wave_unit(F, lane_on);
+    if (unit >= 0 && lane_on) {
         const long long w = unit * 64 + lane;
         int x, y;
         size_t o;
@@ -117,10 +118,10 @@ __global__ __launch_bounds__(RTC_BLOCK, (CSG ? 2 : sizeof(R) == 8 ? RTC_WAVES_F6
             if (F.hit_id) F.hit_id[o] = leaf;
         }
         Q.kids0[w] = kids;
-        if (F.cost && lane == 0) {
-            long long dt = (long long)wall_clock64() - t_start;
-            F.cost[unit] = (uint32_t)(dt < 0 ? 0 : dt > 0x7FFFFFFFLL ? 0x7FFFFFFFLL : dt);
-        }
+    }
+    if (F.cost && unit >= 0 && lane == 0) {
+        long long dt = (long long)wall_clock64() - t_start;
+        atomicAdd(F.cost + unit, (uint32_t)(dt < 0 ? 0 : dt > 0x0FFFFFFFLL ? 0x0FFFFFFFLL : dt));
     }
     flush_counters(cnt, F, reinterpret_cast<unsigned int*>(s_stack));
 }
