@@ -225,6 +225,26 @@ int rtc_quantize_device(const double *rgb_dev, int32_t hsize, int32_t vsize, dou
 int rtc_scatter_tiles_device(const double *tiles_dev, const int32_t *tile_ids_dev, int32_t n_slots, int32_t tile_size,
                              int32_t hsize, int32_t vsize, double *frame_dev, void *stream);
 
+/* max(canvas) of construct_ppm_body's brightness-scaled variant (canvas.py:137-145, np.max over
+ * every component): one double to max_out_dev.  n_values = 3 * hsize * vsize.  Asynchronous. */
+int rtc_frame_max_device(const double *rgb_dev, int64_t n_values, double *max_out_dev, void *stream);
+
+/* construct_ppm_body (canvas.py:133-156) with max_component read on the device: NULL = 1.0
+ * (default_clamping, main.py's final_clamped.ppm), else *max_component_dev (final.ppm, from
+ * rtc_frame_max_device).  out_dev: 3 * hsize * vsize bytes, rows of y, then x, then rgb. */
+int rtc_ppm_body_device(const double *rgb_dev, int32_t hsize, int32_t vsize, const double *max_component_dev,
+                        uint8_t *out_dev, void *stream);
+
+/* render + construct_ppm (main.py:343-354) without the fp64 frame leaving the GPU: traces the
+ * frame, encodes it on the device and copies only the P6 files to the host.  clamped_out /
+ * scaled_out (either may be NULL) each receive a whole file -- header "P6\n<w> <h>\n255\n",
+ * body, trailing newline -- of *length_out bytes; `capacity` is the size of each buffer
+ * (rtc_ppm_size() bytes are enough).  Host buffers; synchronous. */
+int64_t rtc_ppm_size(int32_t hsize, int32_t vsize);
+int rtc_render_ppm(rtc_scene *scene, const rtc_camera *cam, const rtc_render_opts *opts,
+                   uint8_t *clamped_out, uint8_t *scaled_out, int64_t capacity, int64_t *length_out,
+                   rtc_stats *stats_out);
+
 #ifdef __cplusplus
 }
 #endif

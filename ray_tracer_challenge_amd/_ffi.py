@@ -58,7 +58,7 @@ class SceneInfo(C.Structure):
 
 EXPORTS = ["rtc_version", "rtc_device_count", "rtc_last_error", "rtc_scene_create", "rtc_scene_destroy",
            "rtc_scene_get_info", "rtc_render", "rtc_render_tiles", "rtc_render_device", "rtc_quantize_device",
-           "rtc_scatter_tiles_device"]
+           "rtc_scatter_tiles_device", "rtc_frame_max_device", "rtc_ppm_body_device", "rtc_ppm_size", "rtc_render_ppm"]
 
 
 class RtcError(RuntimeError):
@@ -105,6 +105,11 @@ def lib():
         L.rtc_render_device.argtypes = [_P, C.POINTER(CameraDesc), C.POINTER(RenderOpts), C.c_int32, _P, _P, _P, _P, _P]
         L.rtc_quantize_device.argtypes = [_P, C.c_int32, C.c_int32, C.c_double, _P, _P]
         L.rtc_scatter_tiles_device.argtypes = [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P]
+        L.rtc_frame_max_device.argtypes = [_P, C.c_int64, _P, _P]
+        L.rtc_ppm_body_device.argtypes = [_P, C.c_int32, C.c_int32, _P, _P, _P]
+        L.rtc_ppm_size.argtypes = [C.c_int32, C.c_int32]
+        L.rtc_ppm_size.restype = C.c_int64
+        L.rtc_render_ppm.argtypes = [_P, C.POINTER(CameraDesc), C.POINTER(RenderOpts), _P, _P, C.c_int64, C.POINTER(C.c_int64), C.POINTER(Stats)]
         _lib = L
     return _lib
 
@@ -190,6 +195,18 @@ class Scene(object):
                                 ids.ctypes.data_as(_P) if want_ids else None, C.byref(st)))
         _fill_stats(stats, st)
         return rgb, ids
+
+    def render_ppm(self, cam, precision="fp64", max_depth=5, clamped=True, scaled=True, stats=None, seed=0):
+        """-> (final_clamped.ppm bytes or None, final.ppm bytes or None) like main.py:343-354, encoded on the GPU."""
+        c, o, st = make_camera(cam), make_opts(precision, max_depth, 32, 0.0, seed), Stats()
+        size = int(lib().rtc_ppm_size(c.hsize, c.vsize))
+        a = np.empty(size, np.uint8) if clamped else None
+        b = np.empty(size, np.uint8) if scaled else None
+        n = C.c_int64(0)
+        _check(lib().rtc_render_ppm(self.handle, C.byref(c), C.byref(o), a.ctypes.data_as(_P) if clamped else None,
+                                    b.ctypes.data_as(_P) if scaled else None, size, C.byref(n), C.byref(st)))
+        _fill_stats(stats, st)
+        return (a[:n.value].tobytes() if clamped else None, b[:n.value].tobytes() if scaled else None)
 
     def render_tiles(self, cam, tile_ids, precision="fp64", max_depth=5, tile_size=32, want_ids=False, stats=None,
                      shade_eps=0.0, seed=0, wavefront=False, feedback=True):

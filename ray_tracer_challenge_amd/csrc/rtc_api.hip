@@ -161,6 +161,49 @@ __global__ void quantize_kernel(const double* rgb, int hsize, int vsize, double 
     out[i] = (uint8_t)q;
 }
 
+// canvas.py:137-145: np.max over every component.  The result starts as component 0; then one
+// block-level max per workgroup and a compare-and-swap loop that only ever raises it.
+__global__ void frame_max_init_kernel(const double* rgb, double* out) { *out = rgb[0]; }
+__global__ void frame_max_kernel(const double* rgb, long long n, double* out) {
+    __shared__ double red[256 / 64];
+    double m = -INFINITY;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        double v = rgb[i];
+        if (v > m) m = v;
+    }
+    for (int off = 32; off > 0; off >>= 1) { double o = __shfl_down(m, off, 64); if (o > m) m = o; }
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int q = 1; q < 256 / 64; q++) if (red[q] > m) m = red[q];
+        // CAS loop: *out = max(*out, m)
+        unsigned long long* p = reinterpret_cast<unsigned long long*>(out);
+        unsigned long long seen = *p;
+        while (m > __longlong_as_double((long long)seen)) {
+            unsigned long long prev = atomicCAS(p, seen, (unsigned long long)__double_as_longlong(m));
+            if (prev == seen) break;
+            seen = prev;
+        }
+    }
+}
+
+// canvas.py:133-156 with max_component on the device
+__global__ void ppm_body_kernel(const double* rgb, int hsize, int vsize, const double* max_dev, uint8_t* out) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    long long n = (long long)hsize * vsize * 3;
+    if (i >= n) return;
+    const double maxc = max_dev ? *max_dev : 1.0;
+    int c = (int)(i % 3);
+    long long p = i / 3;
+    int x = (int)(p % hsize), y = (int)(p / hsize);
+    double v = rgb[((size_t)x * vsize + y) * 3 + c];
+    int q;
+    if (v >= maxc) q = 255;
+    else if (v <= 0) q = 0;
+    else q = (int)(v * 255 / maxc + 0.5);
+    out[i] = (uint8_t)q;
+}
+
 // compact tiles -> canvas (one thread = one pixel of one slot)
 __global__ void scatter_tiles_kernel(const double* tiles, const int32_t* tile_ids, int n_slots, int T, int tiles_x, int hsize, int vsize, double* frame) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -781,6 +824,81 @@ int rtc_quantize_device(const double* rgb_dev, int32_t hsize, int32_t vsize, dou
     hipLaunchKernelGGL(quantize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), rgb_dev, hsize,
                        vsize, max_component, out_dev);
     HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int rtc_frame_max_device(const double* rgb_dev, int64_t n_values, double* max_out_dev, void* stream) {
+    if (!rgb_dev || !max_out_dev || n_values < 1) return fail(RTC_ERR_INVALID, "bad argument");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(frame_max_init_kernel, dim3(1), dim3(1), 0, st, rgb_dev, max_out_dev);
+    unsigned blocks = (unsigned)std::min<long long>((n_values + 255) / 256, 2048);
+    hipLaunchKernelGGL(frame_max_kernel, dim3(blocks), dim3(256), 0, st, rgb_dev, (long long)n_values, max_out_dev);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int rtc_ppm_body_device(const double* rgb_dev, int32_t hsize, int32_t vsize, const double* max_component_dev, uint8_t* out_dev, void* stream) {
+    if (!rgb_dev || !out_dev || hsize < 1 || vsize < 1) return fail(RTC_ERR_INVALID, "bad argument");
+    long long n = (long long)hsize * vsize * 3;
+    hipLaunchKernelGGL(ppm_body_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), rgb_dev, hsize,
+                       vsize, max_component_dev, out_dev);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int64_t rtc_ppm_size(int32_t hsize, int32_t vsize) {
+    if (hsize < 1 || vsize < 1) return 0;
+    char header[64];
+    int h = snprintf(header, sizeof(header), "P6\n%d %d\n255\n", hsize, vsize);
+    return (int64_t)h + 3LL * hsize * vsize + 1;
+}
+
+int rtc_render_ppm(rtc_scene* scene, const rtc_camera* cam, const rtc_render_opts* opts, uint8_t* clamped_out, uint8_t* scaled_out,
+                   int64_t capacity, int64_t* length_out, rtc_stats* stats_out) {
+    int T, precision, depth;
+    double eps, eps_rel;
+    if (int rc = check_render_args(scene, cam, opts, &T, &precision, &depth, &eps, &eps_rel)) return rc;
+    char header[64];
+    const int hlen = snprintf(header, sizeof(header), "P6\n%d %d\n255\n", cam->hsize, cam->vsize);
+    const size_t n_px = (size_t)cam->hsize * cam->vsize, body = 3 * n_px, total = (size_t)hlen + body + 1;
+    if (length_out) *length_out = (int64_t)total;
+    if ((clamped_out || scaled_out) && capacity < (int64_t)total) return fail(RTC_ERR_INVALID, "ppm buffer too small: %lld < %zu", (long long)capacity, total);
+    if (stats_out) memset(stats_out, 0, sizeof(*stats_out));
+    HIP_TRY(hipSetDevice(scene->device));
+    double* d_rgb = nullptr; double* d_max = nullptr; uint8_t* d_out = nullptr; int64_t* d_rays = nullptr;
+    int rc = 0;
+    auto cleanup = [&]() {
+        if (d_rgb) (void)hipFree(d_rgb);
+        if (d_max) (void)hipFree(d_max);
+        if (d_out) (void)hipFree(d_out);
+        if (d_rays) (void)hipFree(d_rays);
+    };
+#define TRY_C(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { rc = fail(RTC_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); cleanup(); return rc; } } while (0)
+    TRY_C(hipMalloc(&d_rgb, body * sizeof(double)));
+    TRY_C(hipMalloc(&d_max, sizeof(double)));
+    TRY_C(hipMalloc(&d_out, total));
+    TRY_C(hipMalloc(&d_rays, 12 * sizeof(int64_t)));
+    TRY_C(hipMemset(d_rays, 0, 12 * sizeof(int64_t)));
+    const bool want_work = stats_out && opts && (opts->flags & RTC_FLAG_COUNT_WORK);
+    rc = launch(scene, cam, opts, 0, nullptr, d_rgb, nullptr, d_rays, want_work ? d_rays + 4 : nullptr, nullptr);
+    if (rc) { cleanup(); return rc; }
+    TRY_C(hipMemcpy(d_out, header, (size_t)hlen, hipMemcpyHostToDevice));
+    const uint8_t newline = 10;
+    TRY_C(hipMemcpy(d_out + hlen + body, &newline, 1, hipMemcpyHostToDevice));
+    for (int variant = 0; variant < 2; variant++) {
+        uint8_t* dst = variant == 0 ? clamped_out : scaled_out;
+        if (!dst) continue;
+        if (variant == 1) { rc = rtc_frame_max_device(d_rgb, (int64_t)body, d_max, nullptr); if (rc) { cleanup(); return rc; } }
+        rc = rtc_ppm_body_device(d_rgb, cam->hsize, cam->vsize, variant == 1 ? d_max : nullptr, d_out + hlen, nullptr);
+        if (rc) { cleanup(); return rc; }
+        TRY_C(hipMemcpy(dst, d_out, total, hipMemcpyDeviceToHost));
+    }
+    if (stats_out) {
+        TRY_C(hipMemcpy(stats_out->rays, d_rays, 4 * sizeof(int64_t), hipMemcpyDeviceToHost));
+        if (want_work) TRY_C(hipMemcpy(stats_out->work, d_rays + 4, 8 * sizeof(int64_t), hipMemcpyDeviceToHost));
+    }
+#undef TRY_C
+    cleanup();
     return 0;
 }
 

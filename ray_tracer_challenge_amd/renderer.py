@@ -167,6 +167,16 @@ def render(cam, world, precision="fp64", max_depth=5, device=0, return_ids=False
     return (image, ids) if return_ids else image
 
 
+def render_ppm(cam, world, precision="fp64", max_depth=5, clamped=True, scaled=True, device=0):
+    """main.py:343-354 in one call: render, then `construct_ppm(ca)` (final_clamped.ppm) and
+    `construct_ppm(ca, False)` (final.ppm, scaled by the brightest component) -- traced AND encoded on
+    the GPU, so only the two P6 files cross PCIe.  Returns (clamped_bytes | None, scaled_bytes | None)."""
+    from .compile import compile_scene
+    from . import _ffi
+    with _ffi.Scene(compile_scene(world), device=device) as sc:
+        return sc.render_ppm(cam, precision=precision, max_depth=max_depth, clamped=clamped, scaled=scaled)
+
+
 def render_multi(cam, world, num_threads=4, timeout_in_seconds=30, file_path="./", clamping=False,
                  precision="fp64", max_depth=5, devices=None, return_ids=False, stats=None):
     """Same image as `render`, sharded over GPUs (reference renderer.py:795-835).
