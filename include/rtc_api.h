@@ -184,6 +184,17 @@ const char *rtc_last_error(void);
  * GPU `device`.  The caller keeps ownership of every array in `desc`. */
 int rtc_scene_create(const rtc_scene_desc *desc, int device, rtc_scene **out);
 void rtc_scene_destroy(rtc_scene *scene);
+/* the triangle BVH rebuilt on the GPU (Morton codes, radix sort, Karras' radix
+ * tree, bottom-up boxes) from the triangle rows resident on the device, instead of the host's
+ * binned-SAH build of rtc_scene_create.  Same images (any conservative hierarchy gives the
+ * reference's hit lists, shapes.py:454); a millisecond-scale build, a tree that costs rays more
+ * steps.  RTC_ERR_LIMIT (scene unchanged) if the tree is deeper than the traversal stack.
+ * Synchronises the device; do not call while frames of this scene are in flight on other threads. */
+int rtc_scene_build_bvh_device(rtc_scene *scene);
+/* New positions for every triangle of the scene (the animation loops of main.py:240-265): the
+ * tri_geom / tri_norm arrays of rtc_scene_desc again, same triangle count and order, then the GPU
+ * rebuild above.  Everything else of the scene stays. */
+int rtc_scene_update_triangles(rtc_scene *scene, int64_t n_tris, const double *tri_geom, const double *tri_norm);
 int rtc_scene_get_info(const rtc_scene *scene, rtc_scene_info *out);
 
 /* render(cam, world) (renderer.py:753-775).  rgb_out: hsize*vsize*3 doubles in the reference's

@@ -15,6 +15,8 @@
 #include "rtc_bvh.hpp"
 #include "rtc_device.hpp"
 #include "rtc_levels.hpp"
+#include "rtc_lbvh_device.hpp"
+#include <rocprim/rocprim.hpp>
 
 namespace {
 
@@ -275,7 +277,7 @@ struct rtc_scene {
     int device = 0;
     int n_leaves = 0;
     rtc::Bvh bvh_info;   // sizes only (vectors cleared after upload)
-    int bvh_nodes = 0, bvh_depth = 0, bvh_max_leaf = 0;
+    int bvh_nodes = 0, bvh_depth = 0, bvh_max_leaf = 0, obj_depth = 0, obj_max_leaf = 0;
     DeviceArena mem64, mem32, shared;
     rtc::DScene<double> d64;
     rtc::DScene<float> d32;
@@ -296,6 +298,10 @@ struct rtc_scene {
     void* lv_ray = nullptr; double* lv_col = nullptr; int32_t* lv_kids = nullptr; int32_t* lv_kids0 = nullptr; rtc::LvCtrl* lv_ctrl = nullptr;
     long long lv_cap = 0, lv_work = 0;
     bool has_secondary = false;   // some material reflects or refracts
+    // what a GPU rebuild of the triangle BVH needs: the triangle items (prim codes, item order) and the
+    // arena that owns the current triangle BVH (nodes, BVH-ordered rows in both precisions, leaf ids)
+    int32_t* d_titems = nullptr; int n_titems = 0; long long n_tris = 0;
+    DeviceArena tbvh_mem;
     struct FbKey { rtc_camera cam; int32_t precision, depth, tile_size, n_tiles; const int32_t* tile_ids; } fb_key{};
     int fb_age = 0;
 };
@@ -444,6 +450,7 @@ int create_impl(const rtc_scene_desc& d, rtc_scene* sc) {
     if (bvh.depth > RTC_BVH_STACK - 1 || tbvh.depth > RTC_BVH_STACK - 1) return fail(RTC_ERR_LIMIT, "BVH depth exceeds traversal stack");
     sc->bvh_nodes = bvh.n_nodes() + tbvh.n_nodes(); sc->bvh_depth = std::max(bvh.depth, tbvh.depth);
     sc->bvh_max_leaf = std::max(bvh.max_leaf, tbvh.max_leaf);
+    sc->obj_depth = bvh.depth; sc->obj_max_leaf = bvh.max_leaf;
     std::vector<int32_t> prims(oprim.size());
     for (size_t i = 0; i < oprim.size(); i++) prims[i] = oprim[bvh.order[i]];
     // triangles in BVH leaf order: geometry rows + (leaf id | noshadow << 31)
@@ -469,7 +476,12 @@ int create_impl(const rtc_scene_desc& d, rtc_scene* sc) {
     UP(leaf_closed, d.leaf_closed, d.n_leaves);
     UP(tri_leaf, d.tri_leaf, d.n_tris);
     UP(bvh_prims, prims.data(), prims.size());
-    UP(tb_leaf, tb_leaf.data(), tb_leaf.size());
+    if (int rc_ = sc->tbvh_mem.upload(tb_leaf.data(), tb_leaf.size(), &S.tb_leaf)) return rc_;
+    {
+        const int32_t* items_dev = nullptr;
+        if (int rc_ = A.upload(tprim.data(), tprim.size(), &items_dev)) return rc_;
+        sc->d_titems = const_cast<int32_t*>(items_dev); sc->n_titems = (int)tprim.size(); sc->n_tris = d.n_tris;
+    }
     UP(unbounded_prims, d.unbounded_prim, d.n_unbounded);
     UP(csg_root, d.csg_root, 4 * (size_t)d.n_csg_roots);
     UP(csg_node, d.csg_node, 5 * (size_t)d.n_csg_nodes);
@@ -514,11 +526,11 @@ int create_impl(const rtc_scene_desc& d, rtc_scene* sc) {
         };
         std::vector<rtc::BvhNode> on = pack(bvh), tn = pack(tbvh);
         if (int rc = A.upload(on.data(), on.size(), &S.nodes)) return rc;
-        if (int rc = A.upload(tn.data(), tn.size(), &S.tnodes)) return rc;
+        if (int rc = sc->tbvh_mem.upload(tn.data(), tn.size(), &S.tnodes)) return rc;
         F.nodes = S.nodes; F.tnodes = S.tnodes;
-        if (int rc = sc->mem64.upload(tb_geom.data(), tb_geom.size(), &sc->d64.tb_geom)) return rc;
+        if (int rc = sc->tbvh_mem.upload(tb_geom.data(), tb_geom.size(), &sc->d64.tb_geom)) return rc;
         std::vector<float> g32 = cast_vec<float>(tb_geom.data(), tb_geom.size());
-        if (int rc = sc->mem32.upload(g32.data(), g32.size(), &sc->d32.tb_geom)) return rc;
+        if (int rc = sc->tbvh_mem.upload(g32.data(), g32.size(), &sc->d32.tb_geom)) return rc;
     }
     if (int rc = upload_real<double>(d, bvh.box, sc->mem64, sc->d64)) return rc;
     if (int rc = upload_real<float>(d, bvh.box, sc->mem32, sc->d32)) return rc;
@@ -556,6 +568,78 @@ int check_render_args(const rtc_scene* scene, const rtc_camera* cam, const rtc_r
     if (*tile_size < 8 || *tile_size % 8 || *tile_size > 1024) return fail(RTC_ERR_INVALID, "tile_size must be a multiple of 8 in 8..1024");
     *eps = (opts && opts->shade_eps > 0) ? opts->shade_eps : (*precision == 64 ? 0.000001 : 0.00001);
     *eps_rel = (opts && opts->shade_eps_rel >= 0) ? opts->shade_eps_rel : (*precision == 64 ? 0.0 : 0.000001);
+    return 0;
+}
+
+// The triangle BVH rebuilt on the GPU from the resident triangle rows (rtc_lbvh.hpp).  Builds into
+// fresh buffers and swaps them in only if the tree fits the traversal stack.
+int rebuild_triangle_bvh_device(rtc_scene* sc) {
+    const int n = sc->n_titems;
+    if (n == 0) return 0;
+    const int n_leaves = (n + 1) / 2;
+    DeviceArena fresh, temp;
+    auto alloc = [](DeviceArena& A, size_t bytes, void** out) -> int {
+        HIP_TRY(hipMalloc(out, bytes ? bytes : 1));
+        A.ptrs.push_back(*out); A.bytes += bytes;
+        return 0;
+    };
+    void *p_nodes, *p_g64, *p_g32, *p_leaf, *p_boxes, *p_bounds, *p_keys, *p_sorted, *p_lkeys, *p_pin, *p_pleaf, *p_arr, *p_deep, *p_tmp = nullptr;
+    const size_t n_nodes = (size_t)std::max(1, n_leaves - 1);
+    int rc = 0;
+    auto bail = [&](int code) { fresh.release(); temp.release(); return code; };
+    if ((rc = alloc(fresh, n_nodes * sizeof(rtc::BvhNode), &p_nodes)) || (rc = alloc(fresh, 12 * (size_t)n * sizeof(double), &p_g64)) ||
+        (rc = alloc(fresh, 12 * (size_t)n * sizeof(float), &p_g32)) || (rc = alloc(fresh, (size_t)n * sizeof(int32_t), &p_leaf)) ||
+        (rc = alloc(temp, 6 * (size_t)n * sizeof(float), &p_boxes)) || (rc = alloc(temp, 6 * sizeof(uint32_t), &p_bounds)) ||
+        (rc = alloc(temp, (size_t)n * sizeof(uint64_t), &p_keys)) || (rc = alloc(temp, (size_t)n * sizeof(uint64_t), &p_sorted)) ||
+        (rc = alloc(temp, (size_t)n_leaves * sizeof(uint64_t), &p_lkeys)) || (rc = alloc(temp, n_nodes * sizeof(int32_t), &p_pin)) ||
+        (rc = alloc(temp, (size_t)n_leaves * sizeof(int32_t), &p_pleaf)) || (rc = alloc(temp, n_nodes * sizeof(uint32_t), &p_arr)) ||
+        (rc = alloc(temp, sizeof(int32_t), &p_deep)))
+        return bail(rc);
+#define TRY_B(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return bail(fail(RTC_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_))); } while (0)
+    const uint32_t bounds_init[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u};
+    TRY_B(hipMemcpy(p_bounds, bounds_init, sizeof(bounds_init), hipMemcpyHostToDevice));
+    TRY_B(hipMemset(p_pin, 0xFF, n_nodes * sizeof(int32_t)));
+    TRY_B(hipMemset(p_pleaf, 0xFF, (size_t)n_leaves * sizeof(int32_t)));
+    TRY_B(hipMemset(p_arr, 0, n_nodes * sizeof(uint32_t)));
+    TRY_B(hipMemset(p_deep, 0, sizeof(int32_t)));
+    const dim3 blk(256);
+    auto grid_for = [](long long items) { return dim3((unsigned)((items + 255) / 256)); };
+    hipLaunchKernelGGL(rtc::lbvh_boxes_kernel, grid_for(n), blk, 0, nullptr, n, sc->d_titems, sc->d64.tri_geom, (float*)p_boxes, (uint32_t*)p_bounds);
+    hipLaunchKernelGGL(rtc::lbvh_keys_kernel, grid_for(n), blk, 0, nullptr, n, (const float*)p_boxes, (const uint32_t*)p_bounds, (uint64_t*)p_keys);
+    size_t tmp_bytes = 0;
+    TRY_B(rocprim::radix_sort_keys(nullptr, tmp_bytes, (uint64_t*)p_keys, (uint64_t*)p_sorted, (size_t)n, 0, 64, (hipStream_t) nullptr));
+    if ((rc = alloc(temp, tmp_bytes, &p_tmp))) return bail(rc);
+    TRY_B(rocprim::radix_sort_keys(p_tmp, tmp_bytes, (uint64_t*)p_keys, (uint64_t*)p_sorted, (size_t)n, 0, 64, (hipStream_t) nullptr));
+    if (n_leaves == 1) {
+        hipLaunchKernelGGL(rtc::lbvh_single_kernel, dim3(1), dim3(64), 0, nullptr, n, (const uint64_t*)p_sorted, (const float*)p_boxes, (rtc::BvhNode*)p_nodes);
+    } else {
+        hipLaunchKernelGGL(rtc::lbvh_leaf_keys_kernel, grid_for(n_leaves), blk, 0, nullptr, n_leaves, (const uint64_t*)p_sorted, (uint64_t*)p_lkeys);
+        hipLaunchKernelGGL(rtc::lbvh_inner_kernel, grid_for(n_leaves - 1), blk, 0, nullptr, n_leaves, n, (const uint64_t*)p_lkeys, (rtc::BvhNode*)p_nodes,
+                           (int32_t*)p_pin, (int32_t*)p_pleaf);
+        hipLaunchKernelGGL(rtc::lbvh_refit_kernel, grid_for(n_leaves), blk, 0, nullptr, n_leaves, n, (const uint64_t*)p_sorted, (const float*)p_boxes,
+                           (rtc::BvhNode*)p_nodes, (const int32_t*)p_pin, (const int32_t*)p_pleaf, (uint32_t*)p_arr);
+        hipLaunchKernelGGL(rtc::lbvh_depth_kernel, grid_for(n_leaves), blk, 0, nullptr, n_leaves, (const int32_t*)p_pin, (const int32_t*)p_pleaf, (int32_t*)p_deep);
+    }
+    hipLaunchKernelGGL(rtc::lbvh_reorder_kernel, grid_for(12LL * n), blk, 0, nullptr, n, (const uint64_t*)p_sorted, sc->d_titems, sc->d64.tri_geom,
+                       sc->d32.tri_geom, sc->d64.tri_leaf, (double*)p_g64, (float*)p_g32, (int32_t*)p_leaf);
+    TRY_B(hipGetLastError());
+    int32_t deepest = 0;
+    TRY_B(hipMemcpy(&deepest, p_deep, sizeof(deepest), hipMemcpyDeviceToHost));      // also waits for the build
+#undef TRY_B
+    if (n_leaves == 1) deepest = 1;
+    if (deepest > RTC_BVH_STACK - 1) { bail(0); return fail(RTC_ERR_LIMIT, "GPU-built triangle BVH is %d levels deep, the traversal stack holds %d", deepest, RTC_BVH_STACK - 1); }
+    temp.release();
+    sc->tbvh_mem.release();
+    sc->tbvh_mem = fresh;
+    fresh.ptrs.clear();
+    sc->d64.tnodes = sc->d32.tnodes = (const rtc::BvhNode*)p_nodes;
+    sc->d64.n_tnodes = sc->d32.n_tnodes = (int32_t)n_nodes;
+    sc->d64.tb_geom = (const double*)p_g64; sc->d32.tb_geom = (const float*)p_g32;
+    sc->d64.tb_leaf = sc->d32.tb_leaf = (const int32_t*)p_leaf;
+    sc->bvh_nodes = sc->d64.n_bvh_nodes + (int)n_nodes;
+    sc->bvh_depth = std::max(sc->obj_depth, (int)deepest);
+    sc->bvh_max_leaf = std::max(sc->obj_max_leaf, std::min(n, 2));
+    sc->fb_valid = false; sc->fb_age = 0;         // recorded wave costs belong to the old tree
     return 0;
 }
 
@@ -787,10 +871,34 @@ void rtc_scene_destroy(rtc_scene* scene) {
     if (!scene) return;
     (void)hipSetDevice(scene->device);
     scene->shared.release(); scene->mem64.release(); scene->mem32.release();
-    scene->fb_mem.release(); scene->lv_mem.release();
+    scene->fb_mem.release(); scene->lv_mem.release(); scene->tbvh_mem.release();
     if (scene->fb_used_host) (void)hipHostFree(scene->fb_used_host);
     if (scene->fb_used_event) (void)hipEventDestroy(scene->fb_used_event);
     delete scene;
+}
+
+int rtc_scene_build_bvh_device(rtc_scene* scene) {
+    if (!scene) return fail(RTC_ERR_INVALID, "null scene");
+    HIP_TRY(hipSetDevice(scene->device));
+    std::lock_guard<std::mutex> lock(scene->ws_mutex);
+    HIP_TRY(hipDeviceSynchronize());              // no frame of this scene may still be reading the old tree
+    return rebuild_triangle_bvh_device(scene);
+}
+
+int rtc_scene_update_triangles(rtc_scene* scene, int64_t n_tris, const double* tri_geom, const double* tri_norm) {
+    if (!scene || !tri_geom || !tri_norm) return fail(RTC_ERR_INVALID, "null argument");
+    if (n_tris != scene->n_tris) return fail(RTC_ERR_INVALID, "scene has %lld triangles, got %lld", (long long)scene->n_tris, (long long)n_tris);
+    if (n_tris == 0) return 0;
+    HIP_TRY(hipSetDevice(scene->device));
+    std::lock_guard<std::mutex> lock(scene->ws_mutex);
+    HIP_TRY(hipDeviceSynchronize());
+    const size_t n = 12 * (size_t)n_tris;
+    std::vector<float> g32 = cast_vec<float>(tri_geom, n), n32 = cast_vec<float>(tri_norm, n);
+    HIP_TRY(hipMemcpy(const_cast<double*>(scene->d64.tri_geom), tri_geom, n * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(const_cast<double*>(scene->d64.tri_norm), tri_norm, n * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(const_cast<float*>(scene->d32.tri_geom), g32.data(), n * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(const_cast<float*>(scene->d32.tri_norm), n32.data(), n * sizeof(float), hipMemcpyHostToDevice));
+    return rebuild_triangle_bvh_device(scene);
 }
 
 int rtc_scene_get_info(const rtc_scene* scene, rtc_scene_info* out) {

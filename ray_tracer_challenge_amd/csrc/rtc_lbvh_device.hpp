@@ -1,0 +1,134 @@
+// rtc_lbvh_device.hpp -- kernels of the GPU triangle-BVH build (see rtc_lbvh.hpp for what and why).
+// Output: the same BvhNode records (both child boxes as padded fp32 + two child refs) and the same
+// BVH-ordered triangle rows the host builder produces, so the trace kernels do not know the difference.
+#pragma once
+#include "rtc_device.hpp"
+#include "rtc_lbvh.hpp"
+
+namespace rtc {
+
+// floats <-> unsigned ints with the same order (for atomicMin / atomicMax)
+__device__ __forceinline__ uint32_t lbvh_ordered(float f) { uint32_t u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+__device__ __forceinline__ float lbvh_unordered(uint32_t o) { return __uint_as_float((o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o); }
+
+// item k = triangle row items[k] & 0x07FFFFFF: its box, padded outward like the host builder's boxes
+// (2e-5 relative, >= 2e-5 absolute, rounded away), and the bounds of all box centres
+__global__ void lbvh_boxes_kernel(int n, const int32_t* items, const double* tri_geom, float* boxes, uint32_t* bounds /* [6] min xyz, max xyz (ordered) */) {
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const double* g = tri_geom + 12 * (size_t)((uint32_t)items[k] & 0x07FFFFFFu);
+    float lo[3], hi[3];
+    for (int a = 0; a < 3; a++) {
+        double p1 = g[a], p2 = g[a] + g[3 + a], p3 = g[a] + g[6 + a];
+        double l = fmin(p1, fmin(p2, p3)), h = fmax(p1, fmax(p2, p3));
+        l -= 2e-5 * fmax(1.0, fabs(l)); h += 2e-5 * fmax(1.0, fabs(h));
+        lo[a] = __double2float_rd(l); hi[a] = __double2float_ru(h);
+        boxes[6 * (size_t)k + a] = lo[a]; boxes[6 * (size_t)k + 3 + a] = hi[a];
+        float c = 0.5f * (lo[a] + hi[a]);
+        atomicMin(bounds + a, lbvh_ordered(c));
+        atomicMax(bounds + 3 + a, lbvh_ordered(c));
+    }
+}
+
+// key = Morton code of the box centre (30 bits) << 32 | item index: unique, so the radix tree has no ties
+__global__ void lbvh_keys_kernel(int n, const float* boxes, const uint32_t* bounds, uint64_t* keys) {
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    float u[3];
+    for (int a = 0; a < 3; a++) {
+        float lo = lbvh_unordered(bounds[a]), hi = lbvh_unordered(bounds[3 + a]);
+        float c = 0.5f * (boxes[6 * (size_t)k + a] + boxes[6 * (size_t)k + 3 + a]);
+        float ext = hi - lo;
+        u[a] = ext > 0.0f ? (c - lo) / ext : 0.0f;
+    }
+    keys[k] = ((uint64_t)lbvh_morton30(u[0], u[1], u[2]) << 32) | (uint32_t)k;
+}
+
+// leaf j = sorted items 2j and 2j + 1; its key is the first one's
+__global__ void lbvh_leaf_keys_kernel(int n_leaves, const uint64_t* sorted, uint64_t* leaf_keys) {
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n_leaves) leaf_keys[j] = sorted[2 * (size_t)j];
+}
+
+__device__ __forceinline__ int32_t lbvh_leaf_code(int j, int n_items) {
+    int first = 2 * j, count = n_items - first < 2 ? n_items - first : 2;
+    return ~((first << 4) | (count - 1));
+}
+
+// inner node i: children and parent links ((parent << 1) | side)
+__global__ void lbvh_inner_kernel(int n_leaves, int n_items, const uint64_t* leaf_keys, BvhNode* nodes, int32_t* parent_inner, int32_t* parent_leaf) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_leaves - 1) return;
+    int first, last, split;
+    lbvh_inner_node(leaf_keys, n_leaves, i, first, last, split);
+    if (i == 0) parent_inner[0] = -1;
+    int32_t c0, c1;
+    if (split == first) { c0 = lbvh_leaf_code(split, n_items); parent_leaf[split] = (i << 1); }
+    else { c0 = split; parent_inner[split] = (i << 1); }
+    if (split + 1 == last) { c1 = lbvh_leaf_code(split + 1, n_items); parent_leaf[split + 1] = (i << 1) | 1; }
+    else { c1 = split + 1; parent_inner[split + 1] = (i << 1) | 1; }
+    nodes[i].child[0] = c0; nodes[i].child[1] = c1; nodes[i].pad[0] = 0; nodes[i].pad[1] = 0;
+}
+
+// boxes bottom-up: every leaf writes its box into its parent's record and climbs while it is the
+// second child to arrive (the first one stops: its sibling will carry the union up)
+__global__ void lbvh_refit_kernel(int n_leaves, int n_items, const uint64_t* sorted, const float* boxes, BvhNode* nodes, const int32_t* parent_inner,
+                                  const int32_t* parent_leaf, uint32_t* arrived) {
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_leaves) return;
+    float b[6] = {3.0e38f, 3.0e38f, 3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};
+    for (int q = 2 * j; q < 2 * j + 2 && q < n_items; q++) {
+        const float* t = boxes + 6 * (size_t)(uint32_t)(sorted[q] & 0xFFFFFFFFu);
+        for (int a = 0; a < 3; a++) { b[a] = fminf(b[a], t[a]); b[3 + a] = fmaxf(b[3 + a], t[3 + a]); }
+    }
+    int32_t link = parent_leaf[j];
+    while (link >= 0) {
+        const int p = link >> 1, side = link & 1;
+        float* slot = nodes[p].box + 6 * side;
+        for (int a = 0; a < 6; a++) __hip_atomic_store(slot + a, b[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence();
+        if (atomicAdd(arrived + p, 1u) == 0u) return;
+        const float* other = nodes[p].box + 6 * (1 - side);           // written by the sibling's carrier before its atomicAdd
+        for (int a = 0; a < 3; a++) {
+            b[a] = fminf(b[a], __hip_atomic_load(other + a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            b[3 + a] = fmaxf(b[3 + a], __hip_atomic_load(other + 3 + a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        }
+        link = parent_inner[p];
+    }
+}
+
+// a single leaf (1 or 2 triangles): node 0 with one child
+__global__ void lbvh_single_kernel(int n_items, const uint64_t* sorted, const float* boxes, BvhNode* nodes) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    float b[6] = {3.0e38f, 3.0e38f, 3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};
+    for (int q = 0; q < n_items && q < 2; q++) {
+        const float* t = boxes + 6 * (size_t)(uint32_t)(sorted[q] & 0xFFFFFFFFu);
+        for (int a = 0; a < 3; a++) { b[a] = fminf(b[a], t[a]); b[3 + a] = fmaxf(b[3 + a], t[3 + a]); }
+    }
+    for (int a = 0; a < 6; a++) { nodes[0].box[a] = b[a]; nodes[0].box[6 + a] = a < 3 ? 3.0e38f : -3.0e38f; }
+    nodes[0].child[0] = lbvh_leaf_code(0, n_items); nodes[0].child[1] = RTC_EMPTY_CHILD; nodes[0].pad[0] = nodes[0].pad[1] = 0;
+}
+
+// triangle rows into BVH (= sorted) order, both precisions, and leaf id | does-not-cast-shadows << 31
+__global__ void lbvh_reorder_kernel(int n, const uint64_t* sorted, const int32_t* items, const double* geom64, const float* geom32, const int32_t* tri_leaf,
+                                    double* out64, float* out32, int32_t* out_leaf) {
+    long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= 12LL * n) return;
+    int pos = (int)(t / 12), c = (int)(t % 12);
+    uint32_t code = (uint32_t)items[(uint32_t)(sorted[pos] & 0xFFFFFFFFu)];
+    uint32_t row = code & 0x07FFFFFFu;
+    out64[t] = geom64[12 * (size_t)row + c];
+    out32[t] = geom32[12 * (size_t)row + c];
+    if (c == 0) out_leaf[pos] = (int32_t)((uint32_t)tri_leaf[row] | (((code >> 27) & 1u) << 31));
+}
+
+// deepest leaf (inner nodes above it), for the traversal-stack check
+__global__ void lbvh_depth_kernel(int n_leaves, const int32_t* parent_inner, const int32_t* parent_leaf, int32_t* deepest) {
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_leaves) return;
+    int d = 0;
+    for (int32_t link = parent_leaf[j]; link >= 0 && d < 4096; link = parent_inner[link >> 1]) d++;
+    atomicMax(deepest, d);
+}
+
+}  // namespace rtc

@@ -357,3 +357,68 @@ def test_ppm_encoded_on_the_device(name, size, scenes):
         assert rgb.max() > 1.0 and clamped != scaled            # the scene the reference ships with components above 1
     only, none = sc.render_ppm(cam, precision="fp64", scaled=False)
     assert only == clamped and none is None
+
+
+def _same_image(a, b, ia, ib):
+    """Two conservative hierarchies over the same triangles: identical images except where two leaves are hit at exactly
+    the same t (shared edges), which either tree may report first."""
+    assert (np.abs(a - b).max(axis=2) > 1e-9).mean() <= 2e-4
+    assert (ia != ib).mean() <= 2e-4
+
+
+@pytest.mark.parametrize("name,size", [("teapot", None), ("dragons", (480, 192)), ("cover", None)])
+def test_triangle_bvh_built_on_the_gpu(name, size):
+    """rtc_scene_build_bvh_device: same image as with the host-built tree, in both precisions, through the
+    default kernel and the level pipeline; scenes without triangles are left alone."""
+    cam, world, _ = load_pack(name)
+    if size:
+        cam = cam.resized(*size)
+    with _ffi.Scene(compile_scene(world), device=0) as sc:
+        s0, s1 = {}, {}
+        a, ia = sc.render(cam, precision="fp64", want_ids=True, stats=s0)
+        a32, _ = sc.render(cam, precision="fp32")
+        before = sc.info()
+        sc.build_bvh_on_device()
+        after = sc.info()
+        b, ib = sc.render(cam, precision="fp64", want_ids=True, stats=s1)
+        b32, ib32 = sc.render(cam, precision="fp32", want_ids=True)
+        c, ic = sc.render(cam, precision="fp64", want_ids=True, wavefront=True)
+        _same_image(a, b, ia, ib)
+        _same_image(a, c, ia, ic)
+        assert frac_off_by_more_than_one(b32, a) <= 0.001
+        assert abs(sum(s0["rays"]) - sum(s1["rays"])) <= 1e-4 * sum(s0["rays"])
+        if name == "cover":
+            assert after == before                               # no triangles: nothing to rebuild
+        else:
+            assert after["bvh_depth"] <= 31 and after["bvh_nodes"] > 0
+        sc.build_bvh_on_device()                                 # twice in a row: rebuilt from the same rows
+        d, idd = sc.render(cam, precision="fp64", want_ids=True)
+        np.testing.assert_array_equal(b, d)
+
+
+def test_moving_triangles_rebuild_on_the_gpu():
+    """rtc_scene_update_triangles: the teapot moved by new triangle rows + GPU rebuild renders like a scene created with
+    the moved rows (host-built tree)."""
+    cam, world, _ = load_pack("teapot")
+    cam = cam.resized(160, 80)
+    cs = compile_scene(world)
+    off = np.array([0.35, 0.2, -0.15])
+    moved_geom = cs.arrays["tri_geom"].copy().reshape(-1, 12)
+    moved_geom[:, 0:3] += off
+    with _ffi.Scene(cs, device=0) as sc:
+        still, _ = sc.render(cam, precision="fp64")
+        sc.update_triangles(moved_geom, cs.arrays["tri_norm"])
+        got, ids = sc.render(cam, precision="fp64", want_ids=True)
+        got2, _ = sc.render(cam, precision="fp64")                # launch-order feedback restarted for the new tree
+    kinds = (np.asarray(cs.arrays["item_prim"]).astype(np.uint32) >> 28)
+    tri = kinds == 5                                              # RTC_TRIANGLE
+    cs.arrays["tri_geom"] = moved_geom.reshape(cs.arrays["tri_geom"].shape)
+    lo, hi = cs.arrays["item_lo"].copy().reshape(-1, 3), cs.arrays["item_hi"].copy().reshape(-1, 3)
+    lo[tri] += off
+    hi[tri] += off
+    cs.arrays["item_lo"], cs.arrays["item_hi"] = lo.reshape(cs.arrays["item_lo"].shape), hi.reshape(cs.arrays["item_hi"].shape)
+    with _ffi.Scene(cs, device=0) as sc2:
+        want, ids_want = sc2.render(cam, precision="fp64", want_ids=True)
+    assert np.abs(want - still).max() > 0.05                      # it did move
+    _same_image(want, got, ids_want, ids)
+    np.testing.assert_array_equal(got, got2)

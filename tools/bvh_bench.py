@@ -1,0 +1,34 @@
+"""Host-built (binned SAH) vs GPU-built (LBVH) triangle BVH: build time and frame time.  Usage: bvh_bench.py [scene ...]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from ray_tracer_challenge_amd import _ffi
+from ray_tracer_challenge_amd.compile import compile_scene
+from ray_tracer_challenge_amd.scene_io import load_world
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for name in (sys.argv[1:] or ["dragons", "teapot"]):
+    cam, world, _ = load_world(os.path.join(ROOT, "scenes", name + ".npz"))
+    cam = cam.resized(1920, 1080)
+    cs = compile_scene(world)
+    _ffi.Scene(cs).close()                                   # first touch of the device
+    t0 = time.perf_counter()
+    sc = _ffi.Scene(cs)
+    t_create = time.perf_counter() - t0
+    def frame(prec):
+        ms = []
+        for _ in range(6):
+            st = {}
+            sc.render(cam, precision=prec, stats=st)
+            ms.append(st["kernel_ms"])
+        return min(ms[2:])
+    host = (frame("fp64"), frame("fp32"), sc.info())
+    sc.build_bvh_on_device()                                 # warm (allocations, code load)
+    t0 = time.perf_counter()
+    for _ in range(5):
+        sc.build_bvh_on_device()
+    t_build = (time.perf_counter() - t0) / 5
+    dev = (frame("fp64"), frame("fp32"), sc.info())
+    sc.close()
+    print("%-10s %d triangles | rtc_scene_create (host SAH build + upload) %.1f ms | rtc_scene_build_bvh_device %.2f ms" % (
+        name, cs.counts["n_tris"], t_create * 1e3, t_build * 1e3))
+    print("           host tree: depth %d, %d nodes, frame fp64 %.3f ms fp32 %.3f ms | GPU tree: depth %d, %d nodes, frame fp64 %.3f ms fp32 %.3f ms" % (
+        host[2]["bvh_depth"], host[2]["bvh_nodes"], host[0], host[1], dev[2]["bvh_depth"], dev[2]["bvh_nodes"], dev[0], dev[1]), flush=True)
