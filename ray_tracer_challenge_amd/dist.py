@@ -77,6 +77,17 @@ class FrameGather(object):
         else:
             self.compact = torch.zeros((per, tile, tile, 3), dtype=torch.float64, device=device)
 
+    def scatter(self):
+        """rank 0: the gathered tiles -> the canvas."""
+        torch = self.torch
+        if self.on_gpu:
+            from . import _ffi
+            _ffi.scatter_tiles_device(self.all_tiles.data_ptr(), self.slot_tiles.data_ptr(), self.world * self.per, self.tile,
+                                      self.hsize, self.vsize, self.frame.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        else:
+            flat = self.all_tiles.reshape(-1, 3)
+            self.frame.view(-1, 3).index_copy_(0, self.dst, flat.index_select(0, self.src))
+
     def gather(self):
         """After this rank's tiles are in `self.compact`: returns the canvas tensor on rank 0, None elsewhere."""
         torch = self.torch
@@ -85,14 +96,65 @@ class FrameGather(object):
             dist.gather(self.compact, self.gathered if self.rank == 0 else None, dst=0, group=self.group)
             if self.rank != 0:
                 return None
-        if self.on_gpu:
-            from . import _ffi
-            _ffi.scatter_tiles_device(self.all_tiles.data_ptr(), self.slot_tiles.data_ptr(), self.world * self.per, self.tile,
-                                      self.hsize, self.vsize, self.frame.data_ptr(), torch.cuda.current_stream().cuda_stream)
-        else:
-            flat = self.all_tiles.reshape(-1, 3)
-            self.frame.view(-1, 3).index_copy_(0, self.dst, flat.index_select(0, self.src))
+        self.scatter()
         return self.frame
+
+
+class FramePipeline(object):
+    """Frame k's gather overlapped with frame k+1's tracing (a stream of frames: animation, bench).
+
+    Two FrameGather buffer sets alternate.  `submit()` starts the gather of the set just traced as an
+    asynchronous collective (on RCCL's own stream, ordered after the trace kernel) and returns at once;
+    the set is collected -- wait for its gather, tiles -> canvas on rank 0 -- right before it is traced
+    into again, or by `drain()`.  Every frame is whole when `drain()` returns; what changes is that the
+    xGMI transfer no longer sits between two frames' kernels."""
+
+    def __init__(self, hsize, vsize, world, rank, device, tile=TILE, group=None):
+        self.sets = [FrameGather(hsize, vsize, world, rank, device, tile, group) for _ in range(2)]
+        self.pending = [None, None]
+        self.k = 0
+        self.world, self.rank = world, rank
+        self.sets[1].tiles_dev = self.sets[0].tiles_dev      # one tile list: the scene's launch-order feedback is keyed by it
+        if rank == 0:                       # one canvas: frames are assembled in order
+            self.sets[1].frame = self.sets[0].frame
+
+    @property
+    def frame(self):
+        return self.sets[0].frame
+
+    def current(self):
+        """The buffer set to trace the next frame into (collected first if its last gather is still out)."""
+        b = self.k % 2
+        self._collect(b)
+        return self.sets[b]
+
+    def submit(self):
+        """The current set has been traced into: start its gather."""
+        b = self.k % 2
+        fg = self.sets[b]
+        if self.world > 1:
+            import torch.distributed as dist
+            self.pending[b] = dist.gather(fg.compact, fg.gathered if self.rank == 0 else None, dst=0, group=fg.group, async_op=True)
+        else:
+            self.pending[b] = True
+        self.k += 1
+
+    def _collect(self, b):
+        work = self.pending[b]
+        if work is None:
+            return
+        self.pending[b] = None
+        if work is not True:
+            work.wait()
+        if self.rank == 0:
+            self.sets[b].scatter()
+
+    def drain(self):
+        """-> the canvas of the last frame submitted (rank 0), all gathers finished."""
+        first = self.k % 2                  # older set first
+        self._collect(first)
+        self._collect(1 - first)
+        return self.frame if self.rank == 0 else None
 
 
 def render_distributed(scene, cam, fg, precision="fp64", max_depth=5, rays_ptr=None, stream=None, count_work=False):
@@ -102,3 +164,13 @@ def render_distributed(scene, cam, fg, precision="fp64", max_depth=5, rays_ptr=N
                         n_tiles=len(fg.mine), precision=precision, max_depth=max_depth, tile_size=fg.tile,
                         stream=stream, count_work=count_work)
     return fg.gather()
+
+
+def render_pipelined(scene, cam, pipe, precision="fp64", max_depth=5, rays_ptr=None, stream=None, count_work=False):
+    """One frame of a stream of frames: trace this rank's tiles into the pipeline's current buffer set and start its
+    gather; the frame is complete after `pipe.drain()` (or once its set comes round again)."""
+    fg = pipe.current()
+    scene.render_device(cam, fg.compact.data_ptr(), rays_ptr=rays_ptr, tile_ids_ptr=fg.tiles_dev.data_ptr(),
+                        n_tiles=len(fg.mine), precision=precision, max_depth=max_depth, tile_size=fg.tile,
+                        stream=stream, count_work=count_work)
+    pipe.submit()
