@@ -583,7 +583,7 @@ int rebuild_triangle_bvh_device(rtc_scene* sc) {
         A.ptrs.push_back(*out); A.bytes += bytes;
         return 0;
     };
-    void *p_nodes, *p_g64, *p_g32, *p_leaf, *p_boxes, *p_bounds, *p_keys, *p_sorted, *p_lkeys, *p_pin, *p_pleaf, *p_arr, *p_deep, *p_tmp = nullptr;
+    void *p_nodes, *p_g64, *p_g32, *p_leaf, *p_boxes, *p_bounds, *p_keys, *p_sorted, *p_idx, *p_sidx, *p_lkeys, *p_pin, *p_pleaf, *p_arr, *p_deep, *p_tmp = nullptr;
     const size_t n_nodes = (size_t)std::max(1, n_leaves - 1);
     int rc = 0;
     auto bail = [&](int code) { fresh.release(); temp.release(); return code; };
@@ -591,6 +591,7 @@ int rebuild_triangle_bvh_device(rtc_scene* sc) {
         (rc = alloc(fresh, 12 * (size_t)n * sizeof(float), &p_g32)) || (rc = alloc(fresh, (size_t)n * sizeof(int32_t), &p_leaf)) ||
         (rc = alloc(temp, 6 * (size_t)n * sizeof(float), &p_boxes)) || (rc = alloc(temp, 6 * sizeof(uint32_t), &p_bounds)) ||
         (rc = alloc(temp, (size_t)n * sizeof(uint64_t), &p_keys)) || (rc = alloc(temp, (size_t)n * sizeof(uint64_t), &p_sorted)) ||
+        (rc = alloc(temp, (size_t)n * sizeof(uint32_t), &p_idx)) || (rc = alloc(temp, (size_t)n * sizeof(uint32_t), &p_sidx)) ||
         (rc = alloc(temp, (size_t)n_leaves * sizeof(uint64_t), &p_lkeys)) || (rc = alloc(temp, n_nodes * sizeof(int32_t), &p_pin)) ||
         (rc = alloc(temp, (size_t)n_leaves * sizeof(int32_t), &p_pleaf)) || (rc = alloc(temp, n_nodes * sizeof(uint32_t), &p_arr)) ||
         (rc = alloc(temp, sizeof(int32_t), &p_deep)))
@@ -598,33 +599,43 @@ int rebuild_triangle_bvh_device(rtc_scene* sc) {
 #define TRY_B(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return bail(fail(RTC_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_))); } while (0)
     const uint32_t bounds_init[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u};
     TRY_B(hipMemcpy(p_bounds, bounds_init, sizeof(bounds_init), hipMemcpyHostToDevice));
-    TRY_B(hipMemset(p_pin, 0xFF, n_nodes * sizeof(int32_t)));
-    TRY_B(hipMemset(p_pleaf, 0xFF, (size_t)n_leaves * sizeof(int32_t)));
-    TRY_B(hipMemset(p_arr, 0, n_nodes * sizeof(uint32_t)));
-    TRY_B(hipMemset(p_deep, 0, sizeof(int32_t)));
     const dim3 blk(256);
     auto grid_for = [](long long items) { return dim3((unsigned)((items + 255) / 256)); };
     hipLaunchKernelGGL(rtc::lbvh_boxes_kernel, grid_for(n), blk, 0, nullptr, n, sc->d_titems, sc->d64.tri_geom, (float*)p_boxes, (uint32_t*)p_bounds);
-    hipLaunchKernelGGL(rtc::lbvh_keys_kernel, grid_for(n), blk, 0, nullptr, n, (const float*)p_boxes, (const uint32_t*)p_bounds, (uint64_t*)p_keys);
-    size_t tmp_bytes = 0;
-    TRY_B(rocprim::radix_sort_keys(nullptr, tmp_bytes, (uint64_t*)p_keys, (uint64_t*)p_sorted, (size_t)n, 0, 64, (hipStream_t) nullptr));
-    if ((rc = alloc(temp, tmp_bytes, &p_tmp))) return bail(rc);
-    TRY_B(rocprim::radix_sort_keys(p_tmp, tmp_bytes, (uint64_t*)p_keys, (uint64_t*)p_sorted, (size_t)n, 0, 64, (hipStream_t) nullptr));
-    if (n_leaves == 1) {
-        hipLaunchKernelGGL(rtc::lbvh_single_kernel, dim3(1), dim3(64), 0, nullptr, n, (const uint64_t*)p_sorted, (const float*)p_boxes, (rtc::BvhNode*)p_nodes);
-    } else {
-        hipLaunchKernelGGL(rtc::lbvh_leaf_keys_kernel, grid_for(n_leaves), blk, 0, nullptr, n_leaves, (const uint64_t*)p_sorted, (uint64_t*)p_lkeys);
-        hipLaunchKernelGGL(rtc::lbvh_inner_kernel, grid_for(n_leaves - 1), blk, 0, nullptr, n_leaves, n, (const uint64_t*)p_lkeys, (rtc::BvhNode*)p_nodes,
-                           (int32_t*)p_pin, (int32_t*)p_pleaf);
-        hipLaunchKernelGGL(rtc::lbvh_refit_kernel, grid_for(n_leaves), blk, 0, nullptr, n_leaves, n, (const uint64_t*)p_sorted, (const float*)p_boxes,
-                           (rtc::BvhNode*)p_nodes, (const int32_t*)p_pin, (const int32_t*)p_pleaf, (uint32_t*)p_arr);
-        hipLaunchKernelGGL(rtc::lbvh_depth_kernel, grid_for(n_leaves), blk, 0, nullptr, n_leaves, (const int32_t*)p_pin, (const int32_t*)p_pleaf, (int32_t*)p_deep);
+    int32_t deepest = 0;
+    // finest Morton grid first (21 bits per axis); a coarser one if that tree is too deep for the traversal stack
+    const int drop_bits[3] = {0, 18, 33};
+    for (int attempt = 0; attempt < 3; attempt++) {
+        TRY_B(hipMemset(p_pin, 0xFF, n_nodes * sizeof(int32_t)));
+        TRY_B(hipMemset(p_pleaf, 0xFF, (size_t)n_leaves * sizeof(int32_t)));
+        TRY_B(hipMemset(p_arr, 0, n_nodes * sizeof(uint32_t)));
+        TRY_B(hipMemset(p_deep, 0, sizeof(int32_t)));
+        hipLaunchKernelGGL(rtc::lbvh_keys_kernel, grid_for(n), blk, 0, nullptr, n, (const float*)p_boxes, (const uint32_t*)p_bounds, drop_bits[attempt],
+                           (uint64_t*)p_keys, (uint32_t*)p_idx);
+        size_t tmp_bytes = 0;
+        TRY_B(rocprim::radix_sort_pairs(nullptr, tmp_bytes, (uint64_t*)p_keys, (uint64_t*)p_sorted, (uint32_t*)p_idx, (uint32_t*)p_sidx, (size_t)n, 0, 64,
+                                        (hipStream_t) nullptr));
+        if (!p_tmp && (rc = alloc(temp, tmp_bytes, &p_tmp))) return bail(rc);
+        TRY_B(rocprim::radix_sort_pairs(p_tmp, tmp_bytes, (uint64_t*)p_keys, (uint64_t*)p_sorted, (uint32_t*)p_idx, (uint32_t*)p_sidx, (size_t)n, 0, 64,
+                                        (hipStream_t) nullptr));
+        if (n_leaves == 1) {
+            hipLaunchKernelGGL(rtc::lbvh_single_kernel, dim3(1), dim3(64), 0, nullptr, n, (const uint32_t*)p_sidx, (const float*)p_boxes, (rtc::BvhNode*)p_nodes);
+        } else {
+            hipLaunchKernelGGL(rtc::lbvh_leaf_keys_kernel, grid_for(n_leaves), blk, 0, nullptr, n_leaves, (const uint64_t*)p_sorted, (uint64_t*)p_lkeys);
+            hipLaunchKernelGGL(rtc::lbvh_inner_kernel, grid_for(n_leaves - 1), blk, 0, nullptr, n_leaves, n, (const uint64_t*)p_lkeys, (rtc::BvhNode*)p_nodes,
+                               (int32_t*)p_pin, (int32_t*)p_pleaf);
+            hipLaunchKernelGGL(rtc::lbvh_refit_kernel, grid_for(n_leaves), blk, 0, nullptr, n_leaves, n, (const uint32_t*)p_sidx, (const float*)p_boxes,
+                               (rtc::BvhNode*)p_nodes, (const int32_t*)p_pin, (const int32_t*)p_pleaf, (uint32_t*)p_arr);
+            hipLaunchKernelGGL(rtc::lbvh_depth_kernel, grid_for(n_leaves), blk, 0, nullptr, n_leaves, (const int32_t*)p_pin, (const int32_t*)p_pleaf, (int32_t*)p_deep);
+        }
+        TRY_B(hipGetLastError());
+        TRY_B(hipMemcpy(&deepest, p_deep, sizeof(deepest), hipMemcpyDeviceToHost));      // also waits for the build
+        if (n_leaves == 1 || deepest <= RTC_BVH_STACK - 1) break;
     }
-    hipLaunchKernelGGL(rtc::lbvh_reorder_kernel, grid_for(12LL * n), blk, 0, nullptr, n, (const uint64_t*)p_sorted, sc->d_titems, sc->d64.tri_geom,
+    hipLaunchKernelGGL(rtc::lbvh_reorder_kernel, grid_for(12LL * n), blk, 0, nullptr, n, (const uint32_t*)p_sidx, sc->d_titems, sc->d64.tri_geom,
                        sc->d32.tri_geom, sc->d64.tri_leaf, (double*)p_g64, (float*)p_g32, (int32_t*)p_leaf);
     TRY_B(hipGetLastError());
-    int32_t deepest = 0;
-    TRY_B(hipMemcpy(&deepest, p_deep, sizeof(deepest), hipMemcpyDeviceToHost));      // also waits for the build
+    TRY_B(hipDeviceSynchronize());
 #undef TRY_B
     if (n_leaves == 1) deepest = 1;
     if (deepest > RTC_BVH_STACK - 1) { bail(0); return fail(RTC_ERR_LIMIT, "GPU-built triangle BVH is %d levels deep, the traversal stack holds %d", deepest, RTC_BVH_STACK - 1); }

@@ -45,10 +45,37 @@ RTC_HD inline uint32_t lbvh_morton30(float x, float y, float z) {   // x, y, z i
     return (lbvh_expand10(ix) << 2) | (lbvh_expand10(iy) << 1) | lbvh_expand10(iz);
 }
 
-// length of the common prefix of leaf keys i and j (-1 outside the array); keys are unique and sorted
+// 21 bits per axis (63-bit code): ten bits are too coarse once a scene holds several detailed meshes
+RTC_HD inline uint64_t lbvh_expand21(uint64_t v) {
+    v &= 0x1FFFFFull;
+    v = (v | (v << 32)) & 0x001F00000000FFFFull;
+    v = (v | (v << 16)) & 0x001F0000FF0000FFull;
+    v = (v | (v << 8)) & 0x100F00F00F00F00Full;
+    v = (v | (v << 4)) & 0x10C30C30C30C30C3ull;
+    v = (v | (v << 2)) & 0x1249249249249249ull;
+    return v;
+}
+RTC_HD inline uint64_t lbvh_morton63(float x, float y, float z) {   // x, y, z in [0, 1]
+    const double s = 2097152.0;                                        // 2^21
+    double fx = (double)x * s, fy = (double)y * s, fz = (double)z * s;
+    uint64_t ix = fx >= s - 1.0 ? 2097151ull : (fx > 0.0 ? (uint64_t)fx : 0ull);
+    uint64_t iy = fy >= s - 1.0 ? 2097151ull : (fy > 0.0 ? (uint64_t)fy : 0ull);
+    uint64_t iz = fz >= s - 1.0 ? 2097151ull : (fz > 0.0 ? (uint64_t)fz : 0ull);
+    return (lbvh_expand21(ix) << 2) | (lbvh_expand21(iy) << 1) | lbvh_expand21(iz);
+}
+
+// length of the common prefix of leaf keys i and j (-1 outside the array).  Keys are sorted; equal
+// keys are told apart by their position (as if the index were appended to the key), so the tree has no ties.
 RTC_HD inline int lbvh_delta(const uint64_t* keys, int n, int i, int j) {
     if (j < 0 || j >= n) return -1;
-    return lbvh_clz64(keys[i] ^ keys[j]);
+    const uint64_t x = keys[i] ^ keys[j];
+    if (x) return lbvh_clz64(x);
+    uint32_t d = (uint32_t)i ^ (uint32_t)j;
+#if defined(__HIP_DEVICE_COMPILE__)
+    return 64 + (d ? __clz((int)d) : 32);
+#else
+    return 64 + (d ? __builtin_clz(d) : 32);
+#endif
 }
 
 // Karras 2012: inner node i of the radix tree over n sorted leaf keys (n >= 2, 0 <= i < n - 1) covers

@@ -30,8 +30,9 @@ __global__ void lbvh_boxes_kernel(int n, const int32_t* items, const double* tri
     }
 }
 
-// key = Morton code of the box centre (30 bits) << 32 | item index: unique, so the radix tree has no ties
-__global__ void lbvh_keys_kernel(int n, const float* boxes, const uint32_t* bounds, uint64_t* keys) {
+// key = 63-bit Morton code of the box centre, its lowest `drop_bits` bits cleared (a coarser grid makes a
+// shallower tree); value = item index
+__global__ void lbvh_keys_kernel(int n, const float* boxes, const uint32_t* bounds, int drop_bits, uint64_t* keys, uint32_t* index) {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
     float u[3];
@@ -41,7 +42,8 @@ __global__ void lbvh_keys_kernel(int n, const float* boxes, const uint32_t* boun
         float ext = hi - lo;
         u[a] = ext > 0.0f ? (c - lo) / ext : 0.0f;
     }
-    keys[k] = ((uint64_t)lbvh_morton30(u[0], u[1], u[2]) << 32) | (uint32_t)k;
+    keys[k] = (lbvh_morton63(u[0], u[1], u[2]) >> drop_bits) << drop_bits;
+    index[k] = (uint32_t)k;
 }
 
 // leaf j = sorted items 2j and 2j + 1; its key is the first one's
@@ -72,13 +74,13 @@ __global__ void lbvh_inner_kernel(int n_leaves, int n_items, const uint64_t* lea
 
 // boxes bottom-up: every leaf writes its box into its parent's record and climbs while it is the
 // second child to arrive (the first one stops: its sibling will carry the union up)
-__global__ void lbvh_refit_kernel(int n_leaves, int n_items, const uint64_t* sorted, const float* boxes, BvhNode* nodes, const int32_t* parent_inner,
+__global__ void lbvh_refit_kernel(int n_leaves, int n_items, const uint32_t* sorted, const float* boxes, BvhNode* nodes, const int32_t* parent_inner,
                                   const int32_t* parent_leaf, uint32_t* arrived) {
     int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n_leaves) return;
     float b[6] = {3.0e38f, 3.0e38f, 3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};
     for (int q = 2 * j; q < 2 * j + 2 && q < n_items; q++) {
-        const float* t = boxes + 6 * (size_t)(uint32_t)(sorted[q] & 0xFFFFFFFFu);
+        const float* t = boxes + 6 * (size_t)sorted[q];
         for (int a = 0; a < 3; a++) { b[a] = fminf(b[a], t[a]); b[3 + a] = fmaxf(b[3 + a], t[3 + a]); }
     }
     int32_t link = parent_leaf[j];
@@ -98,11 +100,11 @@ __global__ void lbvh_refit_kernel(int n_leaves, int n_items, const uint64_t* sor
 }
 
 // a single leaf (1 or 2 triangles): node 0 with one child
-__global__ void lbvh_single_kernel(int n_items, const uint64_t* sorted, const float* boxes, BvhNode* nodes) {
+__global__ void lbvh_single_kernel(int n_items, const uint32_t* sorted, const float* boxes, BvhNode* nodes) {
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
     float b[6] = {3.0e38f, 3.0e38f, 3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};
     for (int q = 0; q < n_items && q < 2; q++) {
-        const float* t = boxes + 6 * (size_t)(uint32_t)(sorted[q] & 0xFFFFFFFFu);
+        const float* t = boxes + 6 * (size_t)sorted[q];
         for (int a = 0; a < 3; a++) { b[a] = fminf(b[a], t[a]); b[3 + a] = fmaxf(b[3 + a], t[3 + a]); }
     }
     for (int a = 0; a < 6; a++) { nodes[0].box[a] = b[a]; nodes[0].box[6 + a] = a < 3 ? 3.0e38f : -3.0e38f; }
@@ -110,12 +112,12 @@ __global__ void lbvh_single_kernel(int n_items, const uint64_t* sorted, const fl
 }
 
 // triangle rows into BVH (= sorted) order, both precisions, and leaf id | does-not-cast-shadows << 31
-__global__ void lbvh_reorder_kernel(int n, const uint64_t* sorted, const int32_t* items, const double* geom64, const float* geom32, const int32_t* tri_leaf,
+__global__ void lbvh_reorder_kernel(int n, const uint32_t* sorted, const int32_t* items, const double* geom64, const float* geom32, const int32_t* tri_leaf,
                                     double* out64, float* out32, int32_t* out_leaf) {
     long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= 12LL * n) return;
     int pos = (int)(t / 12), c = (int)(t % 12);
-    uint32_t code = (uint32_t)items[(uint32_t)(sorted[pos] & 0xFFFFFFFFu)];
+    uint32_t code = (uint32_t)items[sorted[pos]];
     uint32_t row = code & 0x07FFFFFFu;
     out64[t] = geom64[12 * (size_t)row + c];
     out32[t] = geom32[12 * (size_t)row + c];

@@ -52,7 +52,7 @@ int main() {
             if (trial % 3 == 0) code = (uint32_t)(rng() & 0x3FFFFFFF);                                   // uniform
             else if (trial % 3 == 1) code = (uint32_t)((rng() % 7) * 0x01234567u + (rng() & 0xFF)) & 0x3FFFFFFF;   // clusters
             else code = (uint32_t)(rng() % 3);                                                           // almost all duplicates
-            keys[i] = ((uint64_t)code << 32) | (uint32_t)i;
+            keys[i] = trial % 2 ? ((uint64_t)code << 32) | (uint32_t)i : (uint64_t)code;           // unique keys, or ties broken by position
         }
         std::sort(keys.begin(), keys.end());
         int rc = check(keys);
@@ -61,6 +61,14 @@ int main() {
     }
     // Morton code sanity: monotone in each coordinate's leading bits, within 30 bits
     if (rtc::lbvh_morton30(0, 0, 0) != 0 || rtc::lbvh_morton30(1, 1, 1) != 0x3FFFFFFFu) { printf("FAIL morton ends\n"); return 1; }
+    if (rtc::lbvh_morton63(0, 0, 0) != 0 || rtc::lbvh_morton63(1, 1, 1) != 0x7FFFFFFFFFFFFFFFull) { printf("FAIL morton63 ends\n"); return 1; }
+    if (!(rtc::lbvh_morton63(0.75f, 0, 0) > rtc::lbvh_morton63(0.25f, 1, 1))) { printf("FAIL morton63 order\n"); return 1; }
+    for (int a = 0; a < 3; a++)                       // one axis at a time: its 21 bits land on every third bit
+        for (int bit = 0; bit < 21; bit++) {
+            float v = (float)((1u << bit) + 0.5) / 2097152.0f;
+            uint64_t m = rtc::lbvh_morton63(a == 0 ? v : 0, a == 1 ? v : 0, a == 2 ? v : 0);
+            if (m != (1ull << (3 * bit + (2 - a)))) { printf("FAIL morton63 bit %d axis %d\n", bit, a); return 1; }
+        }
     if (!(rtc::lbvh_morton30(0.75f, 0, 0) > rtc::lbvh_morton30(0.25f, 1, 1))) { printf("FAIL morton order\n"); return 1; }
     printf("OK deepest tree %d\n", worst);
     return 0;
