@@ -184,7 +184,11 @@ template <bool PROF, bool CSG = true> struct Counters {
     static constexpr bool kCsg = CSG;
     unsigned int c[4];
     unsigned int w[PROF ? W_COUNT : 1];
+#ifdef RTC_LANE_STATS   /* development build (tools/lane_stats.py): every counter counts WAVE-level executions, x 65536 */
+    __device__ __forceinline__ void work(int k) { if (PROF) w[k] += 65536u / (unsigned)__popcll(__ballot(1)); }
+#else
     __device__ __forceinline__ void work(int k) { if (PROF) w[k]++; }
+#endif
 };
 #define RTC_EPS R(0.000001) /* renderer.py:15, shapes.py:8 */
 
@@ -389,9 +393,6 @@ __device__ __forceinline__ bool traverse_bvh(const DScene<R>& S, const Ray<R>& r
     while (true) {
         if (node >= 0) {
             vis.cnt.work(W_NODE);
-#ifdef RTC_LANE_STATS   /* development build: W_PATTERN counts wave-level node iterations (x 65536) instead */
-            if (sizeof(vis.cnt.w) > 4) vis.cnt.w[W_PATTERN] += 65536u / (unsigned)__popcll(__ballot(1));
-#endif
             const float4* q = reinterpret_cast<const float4*>(nodes + node);     // 4 x 16-byte loads of one line
             const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
             const float b[12] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w};
