@@ -165,6 +165,8 @@ typedef struct {
                             analytic leaf tests, CSG evaluations, shaded hits, light samples shaded,
                             container passes, pattern evaluations */
     double kernel_ms;    /* trace kernel time measured with HIP events on its stream (host-buffer calls only) */
+    int64_t shadow_rays_culled; /* is_shadowed queries answered without a ray: no cell of the light contributes at
+                            that hit (light behind the surface), so the result is the ambient term either way */
 } rtc_stats;
 
 typedef struct {
@@ -213,8 +215,8 @@ int rtc_render_tiles(rtc_scene *scene, const rtc_camera *cam, const rtc_render_o
 
 /* Device-pointer form for callers that keep the frame in HBM (bench.py, the multi-GPU gather).
  * tile_ids_dev == NULL renders the whole frame into the [x][y][c] layout; otherwise the
- * compact tile layout above.  rays_dev (may be NULL) is ADDED to: [4] int64 ray counts, or [12]
- * with RTC_FLAG_COUNT_WORK ([4..11] = the work counters of rtc_stats).  Asynchronous on
+* compact tile layout above.  rays_dev (may be NULL) is ADDED to and must hold 13 int64: [0..3] ray
+ * counts, [4..11] the work counters of rtc_stats (RTC_FLAG_COUNT_WORK only), [12] shadow rays culled.  Asynchronous on
  * `stream` (a hipStream_t, NULL = default stream).  Render calls on one scene handle must be
  * stream-ordered (same stream, or synchronised by the caller): the handle owns the launch-order
  * buffers of RTC_FLAG_NO_FEEDBACK's comment and the ray pool of RTC_FLAG_WAVEFRONT. */

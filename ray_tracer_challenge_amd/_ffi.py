@@ -48,7 +48,7 @@ class RenderOpts(C.Structure):
 
 
 class Stats(C.Structure):
-    _fields_ = [("rays", C.c_int64 * 4), ("work", C.c_int64 * 8), ("kernel_ms", C.c_double)]
+    _fields_ = [("rays", C.c_int64 * 4), ("work", C.c_int64 * 8), ("kernel_ms", C.c_double), ("shadow_rays_culled", C.c_int64)]
 
 
 class SceneInfo(C.Structure):
@@ -253,6 +253,7 @@ def _fill_stats(stats, st):
         stats["rays"] = [int(v) for v in st.rays]
         stats["work"] = [int(v) for v in st.work]
         stats["kernel_ms"] = float(st.kernel_ms)
+        stats["shadow_rays_culled"] = int(st.shadow_rays_culled)
 
 
 def tiles_for(hsize, vsize, tile_size=32):
@@ -280,6 +281,7 @@ def render_on_devices(cs, cam, devices, precision="fp64", max_depth=5, want_ids=
     rgb = np.zeros((cam.hsize, cam.vsize, 3), np.float64)
     ids = np.full((cam.hsize, cam.vsize), -1, np.int32) if want_ids else None
     total = [0, 0, 0, 0]
+    culled = 0
     for k, dev in enumerate(devices):
         mine = all_tiles[k::len(devices)]
         if mine.size == 0:
@@ -289,6 +291,8 @@ def render_on_devices(cs, cam, devices, precision="fp64", max_depth=5, want_ids=
             r, i = sc.render_tiles(cam, mine, precision, max_depth, tile_size, want_ids, st)
         scatter_tiles(rgb, ids, mine, r, i, tile_size)
         total = [a + b for a, b in zip(total, st["rays"])]
+        culled += st["shadow_rays_culled"]
     if stats is not None:
         stats["rays"] = total
+        stats["shadow_rays_culled"] = culled
     return rgb, ids

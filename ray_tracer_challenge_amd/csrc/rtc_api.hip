@@ -820,8 +820,8 @@ int render_host(rtc_scene* scene, const rtc_camera* cam, const rtc_render_opts* 
     if (tiled) TRY_C(hipMemset(d_rgb, 0, n_px * 3 * sizeof(double)));
     if (hit_id_out) { TRY_C(hipMalloc(&d_id, n_px * sizeof(int32_t))); TRY_C(hipMemset(d_id, 0xFF, n_px * sizeof(int32_t))); }
     const bool want_work = stats_out && opts && (opts->flags & RTC_FLAG_COUNT_WORK);
-    TRY_C(hipMalloc(&d_rays, 12 * sizeof(int64_t)));
-    TRY_C(hipMemset(d_rays, 0, 12 * sizeof(int64_t)));
+    TRY_C(hipMalloc(&d_rays, 13 * sizeof(int64_t)));
+    TRY_C(hipMemset(d_rays, 0, 13 * sizeof(int64_t)));
     if (tiled) {
         TRY_C(hipMalloc(&d_tiles, (size_t)n_tiles * sizeof(int32_t)));
         TRY_C(hipMemcpy(d_tiles, tile_ids, (size_t)n_tiles * sizeof(int32_t), hipMemcpyHostToDevice));
@@ -840,6 +840,7 @@ int render_host(rtc_scene* scene, const rtc_camera* cam, const rtc_render_opts* 
     if (stats_out) {
         TRY_C(hipMemcpy(stats_out->rays, d_rays, 4 * sizeof(int64_t), hipMemcpyDeviceToHost));
         if (want_work) TRY_C(hipMemcpy(stats_out->work, d_rays + 4, 8 * sizeof(int64_t), hipMemcpyDeviceToHost));
+        TRY_C(hipMemcpy(&stats_out->shadow_rays_culled, d_rays + 12, sizeof(int64_t), hipMemcpyDeviceToHost));
         stats_out->kernel_ms = ms;
     }
 #undef TRY_C
@@ -996,8 +997,8 @@ int rtc_render_ppm(rtc_scene* scene, const rtc_camera* cam, const rtc_render_opt
     TRY_C(hipMalloc(&d_rgb, body * sizeof(double)));
     TRY_C(hipMalloc(&d_max, sizeof(double)));
     TRY_C(hipMalloc(&d_out, total));
-    TRY_C(hipMalloc(&d_rays, 12 * sizeof(int64_t)));
-    TRY_C(hipMemset(d_rays, 0, 12 * sizeof(int64_t)));
+    TRY_C(hipMalloc(&d_rays, 13 * sizeof(int64_t)));
+    TRY_C(hipMemset(d_rays, 0, 13 * sizeof(int64_t)));
     const bool want_work = stats_out && opts && (opts->flags & RTC_FLAG_COUNT_WORK);
     rc = launch(scene, cam, opts, 0, nullptr, d_rgb, nullptr, d_rays, want_work ? d_rays + 4 : nullptr, nullptr);
     if (rc) { cleanup(); return rc; }
@@ -1015,6 +1016,7 @@ int rtc_render_ppm(rtc_scene* scene, const rtc_camera* cam, const rtc_render_opt
     if (stats_out) {
         TRY_C(hipMemcpy(stats_out->rays, d_rays, 4 * sizeof(int64_t), hipMemcpyDeviceToHost));
         if (want_work) TRY_C(hipMemcpy(stats_out->work, d_rays + 4, 8 * sizeof(int64_t), hipMemcpyDeviceToHost));
+        TRY_C(hipMemcpy(&stats_out->shadow_rays_culled, d_rays + 12, sizeof(int64_t), hipMemcpyDeviceToHost));
     }
 #undef TRY_C
     cleanup();

@@ -182,7 +182,7 @@ enum { W_NODE = 0, W_TRI = 1, W_LEAF = 2, W_CSG = 3, W_SHADE = 4, W_LIGHT = 5, W
 // carry none of its per-lane hit lists).
 template <bool PROF, bool CSG = true> struct Counters {
     static constexpr bool kCsg = CSG;
-    unsigned int c[4];
+    unsigned int c[5];         // primary, shadow, reflection, refraction rays traced; shadow rays not traced (light behind the surface)
     unsigned int w[PROF ? W_COUNT : 1];
 #ifdef RTC_LANE_STATS   /* development build (tools/lane_stats.py): every counter counts WAVE-level executions, x 65536 */
     __device__ __forceinline__ void work(int k) { if (PROF) w[k] += 65536u / (unsigned)__popcll(__ballot(1)); }
@@ -806,21 +806,23 @@ __device__ __forceinline__ int count_lit(const DScene<R>& S, V3<R> over_point, i
     return lit;
 }
 
-// lighting (renderer.py:1066-1090) for light l given how many of its cells are unshadowed
+// lighting (renderer.py:1066-1090) for light l, in two halves.  light_terms: the ambient term and the mean over the
+// light's cells of the diffuse + specular terms (a FRESH set of surface points, renderer.py:1077 -> 957-962); returns
+// whether any cell contributes at all.  lighting: ambient + mean x (lit cells / cells), ambient alone when no cell is lit
+// (shade_intensity == 0.0).  When no cell contributes -- the light is behind the surface -- the result is the ambient term
+// whatever intensity_at would say, so the caller need not trace those shadow rays.
 template <class R, class CNT>
-__device__ __forceinline__ V3<R> lighting(const DScene<R>& S, const HitCtx<R>& c, V3<R> pcolor, int l, int lit, CNT& cnt, uint64_t seed, uint32_t pixel,
-                                          uint32_t path) {
+__device__ __forceinline__ bool light_terms(const DScene<R>& S, const HitCtx<R>& c, V3<R> pcolor, int l, CNT& cnt, uint64_t seed, uint32_t pixel,
+                                            uint32_t path, V3<R>& amb, V3<R>& mean) {
     const R* m = S.mat + 10 * (size_t)c.material;
     R ambient = m[3], diffuse = m[4], specular = m[5], shininess = m[6];
     const R* li = S.light_intensity + 3 * l;
     V3<R> lint = mk<R>(li[0], li[1], li[2]);
     V3<R> effective = pcolor * lint;
-    V3<R> amb = effective * ambient;
-    if (lit == 0) return amb;                             // shade_intensity == 0.0: ambient only
+    amb = effective * ambient;
     LightShape ls = light_shape(S, l);
-    R intensity = R(lit) / R(ls.samples);
     V3<R> acc = mk<R>(0, 0, 0);
-    for (int v = 0; v < ls.vsteps; v++)                   // a FRESH set of surface points (renderer.py:1077 -> 957-962)
+    for (int v = 0; v < ls.vsteps; v++)
         for (int u = 0; u < ls.usteps; u++) {
             V3<R> pos = light_sample<R>(S, l, ls, u, v, seed, pixel, path, 2);
             cnt.work(W_LIGHT);
@@ -833,7 +835,14 @@ __device__ __forceinline__ V3<R> lighting(const DScene<R>& S, const HitCtx<R>& c
                 if (rde > R(0)) acc = acc + lint * specular * pow_(rde, shininess);
             }
         }
-    return amb + mk<R>(acc.x / R(ls.samples), acc.y / R(ls.samples), acc.z / R(ls.samples)) * intensity;
+    mean = mk<R>(acc.x / R(ls.samples), acc.y / R(ls.samples), acc.z / R(ls.samples));
+    return acc.x != R(0) || acc.y != R(0) || acc.z != R(0);
+}
+template <class R>
+__device__ __forceinline__ V3<R> lighting(const DScene<R>& S, V3<R> amb, V3<R> mean, int l, int lit) {
+    if (lit == 0) return amb;
+    LightShape ls = light_shape(S, l);
+    return amb + mean * (R(lit) / R(ls.samples));
 }
 
 // n1 / n2 from what the container pass found: X = the hit leaf (in `containers` iff x_odd, entered
@@ -929,8 +938,16 @@ __device__ __forceinline__ V3<R> shade_ray(const DScene<R>& S, const Ray<R>& ray
         if (!emit(sec.refl, c.over_point, c.reflectv, sec.w_refl, sec.refr, c.under_point, sec.refr_dir, sec.w_refr)) return surface;
         V3<R> pcolor = surface_color(S, c.material, c.leaf, c.over_point);
         for (int l = 0; l < S.n_lights; l++) {
-            int lit = count_lit(S, c.over_point, l, stack, cnt, seed, pixel, path);
-            surface = surface + lighting(S, c, pcolor, l, lit, cnt, seed, pixel, path);
+            V3<R> amb, mean;
+            const bool matters = light_terms(S, c, pcolor, l, cnt, seed, pixel, path, amb, mean);
+#ifdef RTC_TRACE_ALL_SHADOW_RAYS
+            const int lit = count_lit(S, c.over_point, l, stack, cnt, seed, pixel, path);
+#else
+            int lit = 0;
+            if (matters) lit = count_lit(S, c.over_point, l, stack, cnt, seed, pixel, path);
+            else cnt.c[4] += (unsigned int)light_shape(S, l).samples;
+#endif
+            surface = surface + lighting(S, amb, mean, l, lit);
         }
     }
     return surface;
@@ -997,19 +1014,19 @@ template <class R> __device__ __forceinline__ Ray<R> ray_for_pixel(const DCamera
 
 // block-level reduction of the ray / work counters, then a few atomics per block
 template <bool PROF, bool CSG>
-__device__ __forceinline__ void flush_counters(Counters<PROF, CSG>& cnt, const DFrame& F, unsigned int* red /* LDS, >= 4 * RTC_BLOCK/64 */) {
+__device__ __forceinline__ void flush_counters(Counters<PROF, CSG>& cnt, const DFrame& F, unsigned int* red /* LDS, >= 5 * RTC_BLOCK/64 */) {
     if (F.rays) {
         __syncthreads();
-        for (int k = 0; k < 4; k++) {
+        for (int k = 0; k < 5; k++) {
             unsigned int v = cnt.c[k];
             for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
             if ((threadIdx.x & 63) == 0) red[k * (RTC_BLOCK / 64) + (threadIdx.x >> 6)] = v;
         }
         __syncthreads();
-        if (threadIdx.x < 4) {
+        if (threadIdx.x < 5) {
             unsigned long long s = 0;
             for (int q = 0; q < RTC_BLOCK / 64; q++) s += red[threadIdx.x * (RTC_BLOCK / 64) + q];
-            if (s) atomicAdd(F.rays + threadIdx.x, s);
+            if (s) atomicAdd(F.rays + (threadIdx.x < 4 ? threadIdx.x : 12), s);      // [4..11] are the work counters
         }
     }
     if (PROF && F.work) {
@@ -1021,7 +1038,7 @@ __device__ __forceinline__ void flush_counters(Counters<PROF, CSG>& cnt, const D
     }
 }
 template <bool PROF, bool CSG> __device__ __forceinline__ void zero_counters(Counters<PROF, CSG>& cnt) {
-    for (int k = 0; k < 4; k++) cnt.c[k] = 0;
+    for (int k = 0; k < 5; k++) cnt.c[k] = 0;
     for (int k = 0; k < (PROF ? W_COUNT : 1); k++) cnt.w[k] = 0;
 }
 

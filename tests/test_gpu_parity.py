@@ -36,6 +36,14 @@ def scenes():
         sc.close()
 
 
+def _queries(st):
+    """Ray counts as the reference traces them: is_shadowed queries answered without a ray (light behind the surface: the
+    result is the ambient term either way) count as the shadow rays the reference spends on them."""
+    r = list(st["rays"])
+    r[1] += st["shadow_rays_culled"]
+    return r
+
+
 def _sample(cam, stride):
     xs, ys = np.meshgrid(np.arange(stride // 2, cam.hsize, stride), np.arange(stride // 2, cam.vsize, stride), indexing="ij")
     return xs.ravel(), ys.ravel()
@@ -54,7 +62,8 @@ def test_fp64_matches_oracle(name, size, stride, scenes, oracle_cls):
     assert (ids[px, py] != leaf).mean() <= 0.002
     assert st["rays"][0] == cam.hsize * cam.vsize
     if stride == 1:
-        assert st["rays"] == [int(v) for v in rays]            # same rays traced, kind by kind
+        assert _queries(st) == [int(v) for v in rays]          # same rays, kind by kind
+        assert st["shadow_rays_culled"] >= 0
 
 
 @pytest.mark.parametrize("name", GOLDEN)
@@ -100,7 +109,8 @@ def test_full_size_properties(scenes):
     n_lights = 4
     shaded_primary = int((ids >= 0).sum())
     assert st["rays"][0] == 1920 * 1080
-    assert st["rays"][1] % n_lights == 0 and st["rays"][1] >= n_lights * shaded_primary
+    assert _queries(st)[1] % n_lights == 0 and _queries(st)[1] >= n_lights * shaded_primary
+    assert 0 < st["shadow_rays_culled"] < _queries(st)[1]                      # closed meshes lit from four sides
     assert np.all(full[ids < 0] == 0) and np.isfinite(full).all()
     # idempotence / determinism
     again, _ = sc.render(cam, precision="fp64")
@@ -121,7 +131,7 @@ def test_full_size_properties(scenes):
     st0, st1 = {}, {}
     sc.render(cam, precision="fp64", max_depth=0, stats=st0)
     sc.render(cam, precision="fp64", max_depth=1, stats=st1)
-    assert st0["rays"][2:] == [0, 0] and st0["rays"][1] == n_lights * shaded_primary
+    assert st0["rays"][2:] == [0, 0] and _queries(st0)[1] == n_lights * shaded_primary
     assert st1["rays"][2] <= st["rays"][2] and st1["rays"][3] <= st["rays"][3] and st1["rays"][2] > 0
 
 
@@ -140,7 +150,7 @@ def test_device_pointer_path_and_quantize_kernel(scenes):
     host, _ = sc.render(cam, precision="fp64")
     dev = torch.device("cuda", 0)
     frame = torch.zeros((cam.hsize, cam.vsize, 3), dtype=torch.float64, device=dev)
-    rays = torch.zeros(12, dtype=torch.int64, device=dev)
+    rays = torch.zeros(13, dtype=torch.int64, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
     sc.render_device(cam, frame.data_ptr(), rays_ptr=rays.data_ptr(), precision="fp64", stream=stream)
     torch.cuda.synchronize()
@@ -227,7 +237,7 @@ def test_nested_and_blended_patterns_and_nested_csg(oracle_cls):
         got32, _ = sc.render(cam, precision="fp32")
     np.testing.assert_allclose(got, want, atol=1e-9)
     assert (ids != leaf).mean() <= 0.002
-    assert st["rays"] == [int(v) for v in rays]
+    assert _queries(st) == [int(v) for v in rays]
     # fine stripes / rings / checkers on a plane seen at a grazing angle: fp32 flips the pattern cell on
     # boundary pixels, which is inherent to the precision; this is a torture scene, not a BASELINE config
     assert frac_off_by_more_than_one(got32, want) <= 0.02
