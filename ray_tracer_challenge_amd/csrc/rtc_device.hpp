@@ -133,6 +133,7 @@ template <class R> struct DScene {
     const int32_t* prog_off; const int32_t* prog_len; const int32_t* instr;
     const int64_t* tex_off; const int32_t* tex_w; const int32_t* tex_h; const R* tex_scale; const uint8_t* tex_data;
     int32_t n_lights;
+    int32_t refraction_matters;    // 0 = every material's refractive index is 1: n1 = n2 = 1 at every hit, no container pass needed
     const int32_t* light_type; const R* light_geom; const int32_t* light_steps; const R* light_intensity;
 };
 
@@ -933,7 +934,7 @@ __device__ __forceinline__ V3<R> shade_ray(const DScene<R>& S, const Ray<R>& ray
         HitCtx<R> c = make_ctx(S, ray, nv.best, nv.leaf, nv.u, nv.v, shade_eps, shade_eps_rel);
         if (S.mat_program[c.material] >= 0) cnt.work(W_PATTERN);
         R n1 = R(1), n2 = R(1);
-        if (needs_containers(S.mat[10 * (size_t)c.material + 8], remaining)) container_n1n2(S, ray, c.t, c.leaf, stack, cnt, n1, n2);
+        if (S.refraction_matters && needs_containers(S.mat[10 * (size_t)c.material + 8], remaining)) container_n1n2(S, ray, c.t, c.leaf, stack, cnt, n1, n2);
         Secondary<R> sec = secondary_rays(S, c, remaining, n1, n2);
         if (!emit(sec.refl, c.over_point, c.reflectv, sec.w_refl, sec.refr, c.under_point, sec.refr_dir, sec.w_refr)) return surface;
         V3<R> pcolor = surface_color(S, c.material, c.leaf, c.over_point);
