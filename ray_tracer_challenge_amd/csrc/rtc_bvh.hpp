@@ -12,6 +12,10 @@
 #include <limits>
 #include <vector>
 
+#ifndef RTC_SAH_BINS
+#define RTC_SAH_BINS 16
+#endif
+
 namespace rtc {
 
 struct Aabb {
@@ -105,7 +109,7 @@ private:
         for (int k = 1; k < 3; k++) if (cb.hi[k] - cb.lo[k] > cb.hi[axis] - cb.lo[axis]) axis = k;
         int mid = -1;
         if (!median_ && cb.hi[axis] > cb.lo[axis]) {
-            const int NB = 16;
+            const int NB = RTC_SAH_BINS;
             int best_axis = -1, best_bin = -1;
             double best_cost = std::numeric_limits<double>::infinity();
             for (int ax = 0; ax < 3; ax++) {
