@@ -197,6 +197,13 @@ int rtc_scene_build_bvh_device(rtc_scene *scene);
  * tri_geom / tri_norm arrays of rtc_scene_desc again, same triangle count and order, then the GPU
  * rebuild above.  Everything else of the scene stays. */
 int rtc_scene_update_triangles(rtc_scene *scene, int64_t n_tris, const double *tri_geom, const double *tri_norm);
+/* The same upload, then a REFIT instead of a rebuild: the triangle BVH the scene has now (host SAH
+ * or GPU-built) keeps its nodes and leaves, and its boxes are recomputed bottom-up around the moved
+ * triangles (one kernel, ~0.1 ms).  Right for deformations and small motions, where the SAH tree's
+ * shape stays good; after large relative motion the boxes overlap more and rays slow down (never
+ * wrong: the boxes stay conservative), and rtc_scene_update_triangles is the better call.
+ * Both keep the recorded launch order of the current view and measure it anew. */
+int rtc_scene_refit_triangles(rtc_scene *scene, int64_t n_tris, const double *tri_geom, const double *tri_norm);
 int rtc_scene_get_info(const rtc_scene *scene, rtc_scene_info *out);
 
 /* render(cam, world) (renderer.py:753-775).  rgb_out: hsize*vsize*3 doubles in the reference's

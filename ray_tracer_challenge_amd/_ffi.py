@@ -59,7 +59,7 @@ class SceneInfo(C.Structure):
 EXPORTS = ["rtc_version", "rtc_device_count", "rtc_last_error", "rtc_scene_create", "rtc_scene_destroy",
            "rtc_scene_get_info", "rtc_render", "rtc_render_tiles", "rtc_render_device", "rtc_quantize_device",
            "rtc_scatter_tiles_device", "rtc_frame_max_device", "rtc_ppm_body_device", "rtc_ppm_size", "rtc_render_ppm",
-           "rtc_scene_build_bvh_device", "rtc_scene_update_triangles"]
+           "rtc_scene_build_bvh_device", "rtc_scene_update_triangles", "rtc_scene_refit_triangles"]
 
 
 class RtcError(RuntimeError):
@@ -108,6 +108,7 @@ def lib():
         L.rtc_scatter_tiles_device.argtypes = [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P]
         L.rtc_scene_build_bvh_device.argtypes = [_P]
         L.rtc_scene_update_triangles.argtypes = [_P, C.c_int64, _P, _P]
+        L.rtc_scene_refit_triangles.argtypes = [_P, C.c_int64, _P, _P]
         L.rtc_frame_max_device.argtypes = [_P, C.c_int64, _P, _P]
         L.rtc_ppm_body_device.argtypes = [_P, C.c_int32, C.c_int32, _P, _P, _P]
         L.rtc_ppm_size.argtypes = [C.c_int32, C.c_int32]
@@ -187,11 +188,13 @@ class Scene(object):
         """Replace the host-built triangle BVH by one built on the GPU (rtc_scene_build_bvh_device)."""
         _check(lib().rtc_scene_build_bvh_device(self.handle))
 
-    def update_triangles(self, tri_geom, tri_norm):
-        """New world-space triangle rows (the compiled scene's tri_geom / tri_norm arrays), GPU BVH rebuild."""
+    def update_triangles(self, tri_geom, tri_norm, refit=False):
+        """New world-space triangle rows (the compiled scene's tri_geom / tri_norm arrays), then a GPU rebuild of the
+        triangle BVH, or with refit=True only new boxes on the tree the scene has (rtc_scene_refit_triangles)."""
         g = np.ascontiguousarray(tri_geom, np.float64)
         nn = np.ascontiguousarray(tri_norm, np.float64)
-        _check(lib().rtc_scene_update_triangles(self.handle, g.size // 12, g.ctypes.data_as(_P), nn.ctypes.data_as(_P)))
+        fn = lib().rtc_scene_refit_triangles if refit else lib().rtc_scene_update_triangles
+        _check(fn(self.handle, g.size // 12, g.ctypes.data_as(_P), nn.ctypes.data_as(_P)))
 
     def info(self):
         out = SceneInfo()

@@ -302,6 +302,8 @@ struct rtc_scene {
     // arena that owns the current triangle BVH (nodes, BVH-ordered rows in both precisions, leaf ids)
     int32_t* d_titems = nullptr; int n_titems = 0; long long n_tris = 0;
     DeviceArena tbvh_mem;
+    // for refits (same arena): triangle row at each BVH position, parent link of each node, arrival counters
+    int32_t* d_tb_row = nullptr; int32_t* d_tparent = nullptr; uint32_t* d_tarrived = nullptr;
     struct FbKey { rtc_camera cam; int32_t precision, depth, tile_size, n_tiles; const int32_t* tile_ids; } fb_key{};
     int fb_age = 0;
 };
@@ -460,10 +462,11 @@ int create_impl(const rtc_scene_desc& d, rtc_scene* sc) {
     for (size_t i = 0; i < oprim.size(); i++) prims[i] = oprim[bvh.order[i]];
     // triangles in BVH leaf order: geometry rows + (leaf id | noshadow << 31)
     std::vector<double> tb_geom(12 * tprim.size());
-    std::vector<int32_t> tb_leaf(tprim.size());
+    std::vector<int32_t> tb_leaf(tprim.size()), tb_row(tprim.size());
     for (size_t i = 0; i < tprim.size(); i++) {
         uint32_t code = (uint32_t)tprim[tbvh.order[i]];
         uint32_t row = code & 0x07FFFFFFu;
+        tb_row[i] = (int32_t)row;
         memcpy(&tb_geom[12 * i], d.tri_geom + 12 * (size_t)row, 12 * sizeof(double));
         tb_leaf[i] = (int32_t)((uint32_t)d.tri_leaf[row] | (((code >> 27) & 1u) << 31));
     }
@@ -482,6 +485,20 @@ int create_impl(const rtc_scene_desc& d, rtc_scene* sc) {
     UP(tri_leaf, d.tri_leaf, d.n_tris);
     UP(bvh_prims, prims.data(), prims.size());
     if (int rc_ = sc->tbvh_mem.upload(tb_leaf.data(), tb_leaf.size(), &S.tb_leaf)) return rc_;
+    {
+        std::vector<int32_t> tparent((size_t)tbvh.n_nodes(), -1);
+        for (int i = 0; i < tbvh.n_nodes(); i++)
+            for (int side = 0; side < 2; side++) {
+                int32_t c = tbvh.child[2 * (size_t)i + side];
+                if (c >= 0) tparent[c] = (i << 1) | side;
+            }
+        std::vector<uint32_t> zeros((size_t)tbvh.n_nodes(), 0u);
+        const int32_t* p_row = nullptr; const int32_t* p_par = nullptr; const uint32_t* p_arr = nullptr;
+        if (int rc_ = sc->tbvh_mem.upload(tb_row.data(), tb_row.size(), &p_row)) return rc_;
+        if (int rc_ = sc->tbvh_mem.upload(tparent.data(), tparent.size(), &p_par)) return rc_;
+        if (int rc_ = sc->tbvh_mem.upload(zeros.data(), zeros.size(), &p_arr)) return rc_;
+        sc->d_tb_row = const_cast<int32_t*>(p_row); sc->d_tparent = const_cast<int32_t*>(p_par); sc->d_tarrived = const_cast<uint32_t*>(p_arr);
+    }
     {
         const int32_t* items_dev = nullptr;
         if (int rc_ = A.upload(tprim.data(), tprim.size(), &items_dev)) return rc_;
@@ -590,16 +607,17 @@ int rebuild_triangle_bvh_device(rtc_scene* sc) {
         A.ptrs.push_back(*out); A.bytes += bytes;
         return 0;
     };
-    void *p_nodes, *p_g64, *p_g32, *p_leaf, *p_boxes, *p_bounds, *p_keys, *p_sorted, *p_idx, *p_sidx, *p_lkeys, *p_pin, *p_pleaf, *p_arr, *p_deep, *p_tmp = nullptr;
+    void *p_nodes, *p_g64, *p_g32, *p_leaf, *p_row, *p_arr2, *p_boxes, *p_bounds, *p_keys, *p_sorted, *p_idx, *p_sidx, *p_lkeys, *p_pin, *p_pleaf, *p_arr, *p_deep, *p_tmp = nullptr;
     const size_t n_nodes = (size_t)std::max(1, n_leaves - 1);
     int rc = 0;
     auto bail = [&](int code) { fresh.release(); temp.release(); return code; };
     if ((rc = alloc(fresh, n_nodes * sizeof(rtc::BvhNode), &p_nodes)) || (rc = alloc(fresh, 12 * (size_t)n * sizeof(double), &p_g64)) ||
         (rc = alloc(fresh, 12 * (size_t)n * sizeof(float), &p_g32)) || (rc = alloc(fresh, (size_t)n * sizeof(int32_t), &p_leaf)) ||
+        (rc = alloc(fresh, (size_t)n * sizeof(int32_t), &p_row)) || (rc = alloc(fresh, n_nodes * sizeof(uint32_t), &p_arr2)) ||
         (rc = alloc(temp, 6 * (size_t)n * sizeof(float), &p_boxes)) || (rc = alloc(temp, 6 * sizeof(uint32_t), &p_bounds)) ||
         (rc = alloc(temp, (size_t)n * sizeof(uint64_t), &p_keys)) || (rc = alloc(temp, (size_t)n * sizeof(uint64_t), &p_sorted)) ||
         (rc = alloc(temp, (size_t)n * sizeof(uint32_t), &p_idx)) || (rc = alloc(temp, (size_t)n * sizeof(uint32_t), &p_sidx)) ||
-        (rc = alloc(temp, (size_t)n_leaves * sizeof(uint64_t), &p_lkeys)) || (rc = alloc(temp, n_nodes * sizeof(int32_t), &p_pin)) ||
+        (rc = alloc(temp, (size_t)n_leaves * sizeof(uint64_t), &p_lkeys)) || (rc = alloc(fresh, n_nodes * sizeof(int32_t), &p_pin)) ||
         (rc = alloc(temp, (size_t)n_leaves * sizeof(int32_t), &p_pleaf)) || (rc = alloc(temp, n_nodes * sizeof(uint32_t), &p_arr)) ||
         (rc = alloc(temp, sizeof(int32_t), &p_deep)))
         return bail(rc);
@@ -640,7 +658,7 @@ int rebuild_triangle_bvh_device(rtc_scene* sc) {
         if (n_leaves == 1 || deepest <= RTC_BVH_STACK - 1) break;
     }
     hipLaunchKernelGGL(rtc::lbvh_reorder_kernel, grid_for(12LL * n), blk, 0, nullptr, n, (const uint32_t*)p_sidx, sc->d_titems, sc->d64.tri_geom,
-                       sc->d32.tri_geom, sc->d64.tri_leaf, (double*)p_g64, (float*)p_g32, (int32_t*)p_leaf);
+                       sc->d32.tri_geom, sc->d64.tri_leaf, (double*)p_g64, (float*)p_g32, (int32_t*)p_leaf, (int32_t*)p_row);
     TRY_B(hipGetLastError());
     TRY_B(hipDeviceSynchronize());
 #undef TRY_B
@@ -654,10 +672,28 @@ int rebuild_triangle_bvh_device(rtc_scene* sc) {
     sc->d64.n_tnodes = sc->d32.n_tnodes = (int32_t)n_nodes;
     sc->d64.tb_geom = (const double*)p_g64; sc->d32.tb_geom = (const float*)p_g32;
     sc->d64.tb_leaf = sc->d32.tb_leaf = (const int32_t*)p_leaf;
+    sc->d_tb_row = (int32_t*)p_row; sc->d_tparent = (int32_t*)p_pin; sc->d_tarrived = (uint32_t*)p_arr2;
     sc->bvh_nodes = sc->d64.n_bvh_nodes + (int)n_nodes;
     sc->bvh_depth = std::max(sc->obj_depth, (int)deepest);
     sc->bvh_max_leaf = std::max(sc->obj_max_leaf, std::min(n, 2));
-    sc->fb_valid = false; sc->fb_age = 0;         // recorded wave costs belong to the old tree
+    sc->fb_age = std::min(sc->fb_age, 1);         // the launch order stays (any order renders the same image); costs are recorded anew
+    return 0;
+}
+
+// The triangle BVH refitted on the GPU: same nodes, same leaves, new boxes around the rows now in the triangle table.
+int refit_triangle_bvh_device(rtc_scene* sc) {
+    const int n = sc->n_titems, n_nodes = sc->d64.n_tnodes;
+    if (n == 0 || n_nodes == 0) return 0;
+    if (!sc->d_tb_row || !sc->d_tparent || !sc->d_tarrived) return fail(RTC_ERR_HIP, "internal: refit tables missing");
+    const dim3 blk(256);
+    HIP_TRY(hipMemset(sc->d_tarrived, 0, (size_t)n_nodes * sizeof(uint32_t)));
+    hipLaunchKernelGGL(rtc::bvh_gather_rows_kernel, dim3((unsigned)((12LL * n + 255) / 256)), blk, 0, nullptr, n, (const int32_t*)sc->d_tb_row,
+                       sc->d64.tri_geom, sc->d32.tri_geom, const_cast<double*>(sc->d64.tb_geom), const_cast<float*>(sc->d32.tb_geom));
+    hipLaunchKernelGGL(rtc::bvh_refit_kernel, dim3((unsigned)((n_nodes + 255) / 256)), blk, 0, nullptr, n_nodes, const_cast<rtc::BvhNode*>(sc->d64.tnodes),
+                       (const int32_t*)sc->d_tparent, sc->d64.tb_geom, sc->d_tarrived);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    sc->fb_age = std::min(sc->fb_age, 1);
     return 0;
 }
 
@@ -904,7 +940,22 @@ int rtc_scene_build_bvh_device(rtc_scene* scene) {
     return rebuild_triangle_bvh_device(scene);
 }
 
+namespace {
+int update_triangles_impl(rtc_scene* scene, int64_t n_tris, const double* tri_geom, const double* tri_norm, bool refit);
+}
+
 int rtc_scene_update_triangles(rtc_scene* scene, int64_t n_tris, const double* tri_geom, const double* tri_norm) {
+    return update_triangles_impl(scene, n_tris, tri_geom, tri_norm, false);
+}
+
+int rtc_scene_refit_triangles(rtc_scene* scene, int64_t n_tris, const double* tri_geom, const double* tri_norm) {
+    return update_triangles_impl(scene, n_tris, tri_geom, tri_norm, true);
+}
+
+}  // extern "C"
+
+namespace {
+int update_triangles_impl(rtc_scene* scene, int64_t n_tris, const double* tri_geom, const double* tri_norm, bool refit) {
     if (!scene || !tri_geom || !tri_norm) return fail(RTC_ERR_INVALID, "null argument");
     if (n_tris != scene->n_tris) return fail(RTC_ERR_INVALID, "scene has %lld triangles, got %lld", (long long)scene->n_tris, (long long)n_tris);
     if (n_tris == 0) return 0;
@@ -917,8 +968,11 @@ int rtc_scene_update_triangles(rtc_scene* scene, int64_t n_tris, const double* t
     HIP_TRY(hipMemcpy(const_cast<double*>(scene->d64.tri_norm), tri_norm, n * sizeof(double), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(const_cast<float*>(scene->d32.tri_geom), g32.data(), n * sizeof(float), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(const_cast<float*>(scene->d32.tri_norm), n32.data(), n * sizeof(float), hipMemcpyHostToDevice));
-    return rebuild_triangle_bvh_device(scene);
+    return refit ? refit_triangle_bvh_device(scene) : rebuild_triangle_bvh_device(scene);
 }
+}  // namespace
+
+extern "C" {
 
 int rtc_scene_get_info(const rtc_scene* scene, rtc_scene_info* out) {
     if (!scene || !out) return fail(RTC_ERR_INVALID, "null argument");

@@ -111,9 +111,10 @@ __global__ void lbvh_single_kernel(int n_items, const uint32_t* sorted, const fl
     nodes[0].child[0] = lbvh_leaf_code(0, n_items); nodes[0].child[1] = RTC_EMPTY_CHILD; nodes[0].pad[0] = nodes[0].pad[1] = 0;
 }
 
-// triangle rows into BVH (= sorted) order, both precisions, and leaf id | does-not-cast-shadows << 31
+// triangle rows into BVH (= sorted) order, both precisions, leaf id | does-not-cast-shadows << 31, and
+// which row went where (for refits)
 __global__ void lbvh_reorder_kernel(int n, const uint32_t* sorted, const int32_t* items, const double* geom64, const float* geom32, const int32_t* tri_leaf,
-                                    double* out64, float* out32, int32_t* out_leaf) {
+                                    double* out64, float* out32, int32_t* out_leaf, int32_t* out_row) {
     long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= 12LL * n) return;
     int pos = (int)(t / 12), c = (int)(t % 12);
@@ -121,7 +122,7 @@ __global__ void lbvh_reorder_kernel(int n, const uint32_t* sorted, const int32_t
     uint32_t row = code & 0x07FFFFFFu;
     out64[t] = geom64[12 * (size_t)row + c];
     out32[t] = geom32[12 * (size_t)row + c];
-    if (c == 0) out_leaf[pos] = (int32_t)((uint32_t)tri_leaf[row] | (((code >> 27) & 1u) << 31));
+    if (c == 0) { out_leaf[pos] = (int32_t)((uint32_t)tri_leaf[row] | (((code >> 27) & 1u) << 31)); out_row[pos] = (int32_t)row; }
 }
 
 // deepest leaf (inner nodes above it), for the traversal-stack check
@@ -131,6 +132,63 @@ __global__ void lbvh_depth_kernel(int n_leaves, const int32_t* parent_inner, con
     int d = 0;
     for (int32_t link = parent_leaf[j]; link >= 0 && d < 4096; link = parent_inner[link >> 1]) d++;
     atomicMax(deepest, d);
+}
+
+// ---- refit: the tree keeps its shape (whichever builder made it), only the boxes follow the triangles ----
+
+// BVH-ordered rows refreshed from the triangle table: position pos holds row row_of[pos]
+__global__ void bvh_gather_rows_kernel(int n, const int32_t* row_of, const double* geom64, const float* geom32, double* out64, float* out32) {
+    long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= 12LL * n) return;
+    int pos = (int)(t / 12), c = (int)(t % 12);
+    size_t src = 12 * (size_t)row_of[pos] + c;
+    out64[t] = geom64[src];
+    out32[t] = geom32[src];
+}
+
+// One thread per node: it boxes the node's leaf children from their (BVH-ordered) rows, padded like the builders'
+// boxes, and counts itself as arrived; a node is complete once its own thread and the carriers of its inner
+// children have arrived, and whoever arrives last carries the union of its two boxes up into the parent's record.
+// parent[i] = (parent node << 1) | side, -1 for the root; arrived[] zeroed by the caller.
+__global__ void bvh_refit_kernel(int n_nodes, BvhNode* nodes, const int32_t* parent, const double* tb_geom, uint32_t* arrived) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_nodes) return;
+    for (int side = 0; side < 2; side++) {
+        const int32_t c = nodes[i].child[side];
+        if (c >= 0 || c == RTC_EMPTY_CHILD) continue;
+        const int first = (~c) >> 4, count = ((~c) & 15) + 1;
+        float* slot = nodes[i].box + 6 * side;
+        for (int a = 0; a < 3; a++) {
+            double l = 1.0e300, h = -1.0e300;
+            for (int q = first; q < first + count; q++) {
+                const double* g = tb_geom + 12 * (size_t)q;
+                double p1 = g[a], p2 = g[a] + g[3 + a], p3 = g[a] + g[6 + a];
+                l = fmin(l, fmin(p1, fmin(p2, p3))); h = fmax(h, fmax(p1, fmax(p2, p3)));
+            }
+            l -= 2e-5 * fmax(1.0, fabs(l)); h += 2e-5 * fmax(1.0, fabs(h));
+            __hip_atomic_store(slot + a, __double2float_rd(l), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(slot + 3 + a, __double2float_ru(h), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    int p = i;
+    for (int guard = 0; guard < 4096; guard++) {
+        __threadfence();
+        const uint32_t needed = 1u + (nodes[p].child[0] >= 0 ? 1u : 0u) + (nodes[p].child[1] >= 0 ? 1u : 0u);
+        if (atomicAdd(arrived + p, 1u) + 1u != needed) return;
+        const int32_t link = parent[p];
+        if (link < 0) return;
+        float b[6];
+        for (int a = 0; a < 3; a++) {
+            b[a] = fminf(__hip_atomic_load(nodes[p].box + a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                         __hip_atomic_load(nodes[p].box + 6 + a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            b[3 + a] = fmaxf(__hip_atomic_load(nodes[p].box + 3 + a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                             __hip_atomic_load(nodes[p].box + 9 + a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        }
+        const int q = link >> 1;
+        float* slot = nodes[q].box + 6 * (link & 1);
+        for (int a = 0; a < 6; a++) __hip_atomic_store(slot + a, b[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        p = q;
+    }
 }
 
 }  // namespace rtc

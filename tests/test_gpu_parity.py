@@ -406,9 +406,10 @@ def test_triangle_bvh_built_on_the_gpu(name, size):
         np.testing.assert_array_equal(b, d)
 
 
-def test_moving_triangles_rebuild_on_the_gpu():
-    """rtc_scene_update_triangles: the teapot moved by new triangle rows + GPU rebuild renders like a scene created with
-    the moved rows (host-built tree)."""
+@pytest.mark.parametrize("refit", [False, True], ids=["rebuild", "refit"])
+def test_moving_triangles_rebuild_on_the_gpu(refit):
+    """rtc_scene_update_triangles / rtc_scene_refit_triangles: the teapot moved by new triangle rows + GPU rebuild (or
+    refit of the host-built tree) renders like a scene created with the moved rows (host-built tree)."""
     cam, world, _ = load_pack("teapot")
     cam = cam.resized(160, 80)
     cs = compile_scene(world)
@@ -417,7 +418,7 @@ def test_moving_triangles_rebuild_on_the_gpu():
     moved_geom[:, 0:3] += off
     with _ffi.Scene(cs, device=0) as sc:
         still, _ = sc.render(cam, precision="fp64")
-        sc.update_triangles(moved_geom, cs.arrays["tri_norm"])
+        sc.update_triangles(moved_geom, cs.arrays["tri_norm"], refit=refit)
         got, ids = sc.render(cam, precision="fp64", want_ids=True)
         got2, _ = sc.render(cam, precision="fp64")                # launch-order feedback restarted for the new tree
     kinds = (np.asarray(cs.arrays["item_prim"]).astype(np.uint32) >> 28)
@@ -432,3 +433,55 @@ def test_moving_triangles_rebuild_on_the_gpu():
     assert np.abs(want - still).max() > 0.05                      # it did move
     _same_image(want, got, ids_want, ids)
     np.testing.assert_array_equal(got, got2)
+
+
+def test_refit_follows_a_deforming_mesh():
+    """rtc_scene_refit_triangles on both kinds of tree: every triangle of the teapot displaced by its own amount (a
+    deformation, not a rigid motion), refitted twice in a row (host SAH tree, then the GPU-built tree), both precisions
+    and the level pipeline, against a scene created from the deformed rows."""
+    cam, world, _ = load_pack("teapot")
+    cam = cam.resized(200, 100)
+    cs = compile_scene(world)
+    g0 = cs.arrays["tri_geom"].copy().reshape(-1, 12)
+    rng = np.random.default_rng(5)
+
+    def deformed(amount):
+        g = g0.copy()
+        c = g[:, 0:3] + (g[:, 3:6] + g[:, 6:9]) / 3.0
+        g[:, 0:3] += amount * np.sin(3.0 * c[:, [1, 2, 0]]) + 0.02 * amount * rng.standard_normal((len(g), 3))
+        return g
+
+    def fresh(g):
+        cs2 = compile_scene(world)
+        kinds = (np.asarray(cs2.arrays["item_prim"]).astype(np.uint32) >> 28)
+        rows = np.asarray(cs2.arrays["item_prim"]).astype(np.uint32)[kinds == 5] & 0x07FFFFFF
+        p1, p2, p3 = g[rows, 0:3], g[rows, 0:3] + g[rows, 3:6], g[rows, 0:3] + g[rows, 6:9]
+        lo, hi = cs2.arrays["item_lo"].copy().reshape(-1, 3), cs2.arrays["item_hi"].copy().reshape(-1, 3)
+        lo[kinds == 5] = np.minimum(np.minimum(p1, p2), p3)
+        hi[kinds == 5] = np.maximum(np.maximum(p1, p2), p3)
+        cs2.arrays["tri_geom"] = g.reshape(cs2.arrays["tri_geom"].shape)
+        cs2.arrays["item_lo"], cs2.arrays["item_hi"] = lo.reshape(cs2.arrays["item_lo"].shape), hi.reshape(cs2.arrays["item_hi"].shape)
+        with _ffi.Scene(cs2, device=0) as sc2:
+            return sc2.render(cam, precision="fp64", want_ids=True)
+
+    g1, g2 = deformed(0.25), deformed(0.6)
+    want1, ids1 = fresh(g1)
+    want2, ids2 = fresh(g2)
+    assert np.abs(want1 - want2).max() > 0.05
+    with _ffi.Scene(cs, device=0) as sc:
+        before = sc.info()
+        sc.update_triangles(g1, cs.arrays["tri_norm"], refit=True)            # host SAH tree refitted
+        assert sc.info() == before                                             # same tree, new boxes
+        a, ia = sc.render(cam, precision="fp64", want_ids=True)
+        a32, _ = sc.render(cam, precision="fp32")
+        _same_image(want1, a, ids1, ia)
+        assert frac_off_by_more_than_one(a32, want1) <= 0.001
+        sc.update_triangles(g2, cs.arrays["tri_norm"], refit=True)            # and again, further
+        b, ib = sc.render(cam, precision="fp64", want_ids=True)
+        c, ic = sc.render(cam, precision="fp64", want_ids=True, wavefront=True)
+        _same_image(want2, b, ids2, ib)
+        _same_image(want2, c, ids2, ic)
+        sc.build_bvh_on_device()                                               # GPU-built tree over g2 ...
+        sc.update_triangles(g1, cs.arrays["tri_norm"], refit=True)            # ... refitted back to g1
+        d, idd = sc.render(cam, precision="fp64", want_ids=True)
+        _same_image(want1, d, ids1, idd)

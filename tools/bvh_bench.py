@@ -1,5 +1,6 @@
 """Host-built (binned SAH) vs GPU-built (LBVH) triangle BVH: build time and frame time.  Usage: bvh_bench.py [scene ...]"""
 import os, sys, time
+import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ray_tracer_challenge_amd import _ffi
 from ray_tracer_challenge_amd.compile import compile_scene
@@ -21,6 +22,26 @@ for name in (sys.argv[1:] or ["dragons", "teapot"]):
             ms.append(st["kernel_ms"])
         return min(ms[2:])
     host = (frame("fp64"), frame("fp32"), sc.info())
+    # refit of the host tree after a smooth deformation (amplitude as a fraction of the mesh extent)
+    g0 = np.asarray(cs.arrays["tri_geom"], np.float64).reshape(-1, 12)
+    nrm = cs.arrays["tri_norm"]
+    ext = float((g0[:, 0:3].max(axis=0) - g0[:, 0:3].min(axis=0)).max())
+    refits = []
+    for amp in (0.0, 0.01, 0.05, 0.2):
+        g = g0.copy()
+        g[:, 0:3] += amp * ext * np.sin((6.0 / ext) * g0[:, [1, 2, 0]])
+        sc.update_triangles(g, nrm, refit=True)
+        t0 = time.perf_counter()
+        sc.update_triangles(g, nrm, refit=True)
+        t_refit = time.perf_counter() - t0
+        f_refit = frame("fp64")
+        sc.update_triangles(g, nrm)
+        t0 = time.perf_counter()
+        sc.update_triangles(g, nrm)
+        t_upd = time.perf_counter() - t0
+        refits.append((amp, t_refit * 1e3, f_refit, t_upd * 1e3, frame("fp64")))
+        sc.close()
+        sc = _ffi.Scene(cs)                                  # back to the host SAH tree
     sc.build_bvh_on_device()                                 # warm (allocations, code load)
     t0 = time.perf_counter()
     for _ in range(5):
@@ -32,3 +53,6 @@ for name in (sys.argv[1:] or ["dragons", "teapot"]):
         name, cs.counts["n_tris"], t_create * 1e3, t_build * 1e3))
     print("           host tree: depth %d, %d nodes, frame fp64 %.3f ms fp32 %.3f ms | GPU tree: depth %d, %d nodes, frame fp64 %.3f ms fp32 %.3f ms" % (
         host[2]["bvh_depth"], host[2]["bvh_nodes"], host[0], host[1], dev[2]["bvh_depth"], dev[2]["bvh_nodes"], dev[0], dev[1]), flush=True)
+    for amp, t_refit, f_refit, t_upd, f_upd in refits:
+        print("           deformed by %4.0f %% of the extent: upload + refit %.2f ms -> frame fp64 %.3f ms | upload + rebuild %.2f ms -> frame %.3f ms" % (
+            100 * amp, t_refit, f_refit, t_upd, f_upd), flush=True)
