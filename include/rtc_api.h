@@ -204,6 +204,10 @@ int rtc_scene_update_triangles(rtc_scene *scene, int64_t n_tris, const double *t
  * wrong: the boxes stay conservative), and rtc_scene_update_triangles is the better call.
  * Both keep the recorded launch order of the current view and measure it anew. */
 int rtc_scene_refit_triangles(rtc_scene *scene, int64_t n_tris, const double *tri_geom, const double *tri_norm);
+/* Either of the two with the new rows already in device memory on the scene's GPU (fp64, same
+ * layout; written before this call on the null stream or synchronised by the caller): no PCIe
+ * copy.  refit != 0 -> refit, else rebuild. */
+int rtc_scene_update_triangles_device(rtc_scene *scene, int64_t n_tris, const double *tri_geom_dev, const double *tri_norm_dev, int refit);
 int rtc_scene_get_info(const rtc_scene *scene, rtc_scene_info *out);
 
 /* render(cam, world) (renderer.py:753-775).  rgb_out: hsize*vsize*3 doubles in the reference's

@@ -59,7 +59,7 @@ class SceneInfo(C.Structure):
 EXPORTS = ["rtc_version", "rtc_device_count", "rtc_last_error", "rtc_scene_create", "rtc_scene_destroy",
            "rtc_scene_get_info", "rtc_render", "rtc_render_tiles", "rtc_render_device", "rtc_quantize_device",
            "rtc_scatter_tiles_device", "rtc_frame_max_device", "rtc_ppm_body_device", "rtc_ppm_size", "rtc_render_ppm",
-           "rtc_scene_build_bvh_device", "rtc_scene_update_triangles", "rtc_scene_refit_triangles"]
+           "rtc_scene_build_bvh_device", "rtc_scene_update_triangles", "rtc_scene_refit_triangles", "rtc_scene_update_triangles_device"]
 
 
 class RtcError(RuntimeError):
@@ -109,6 +109,7 @@ def lib():
         L.rtc_scene_build_bvh_device.argtypes = [_P]
         L.rtc_scene_update_triangles.argtypes = [_P, C.c_int64, _P, _P]
         L.rtc_scene_refit_triangles.argtypes = [_P, C.c_int64, _P, _P]
+        L.rtc_scene_update_triangles_device.argtypes = [_P, C.c_int64, _P, _P, C.c_int]
         L.rtc_frame_max_device.argtypes = [_P, C.c_int64, _P, _P]
         L.rtc_ppm_body_device.argtypes = [_P, C.c_int32, C.c_int32, _P, _P, _P]
         L.rtc_ppm_size.argtypes = [C.c_int32, C.c_int32]
@@ -195,6 +196,11 @@ class Scene(object):
         nn = np.ascontiguousarray(tri_norm, np.float64)
         fn = lib().rtc_scene_refit_triangles if refit else lib().rtc_scene_update_triangles
         _check(fn(self.handle, g.size // 12, g.ctypes.data_as(_P), nn.ctypes.data_as(_P)))
+
+    def update_triangles_device(self, geom_ptr, norm_ptr, n_tris, refit=False):
+        """The same with the rows already on this scene's GPU: device pointers (e.g. torch tensors' data_ptr()) to
+        n_tris x 12 fp64 each; the caller synchronises whatever wrote them."""
+        _check(lib().rtc_scene_update_triangles_device(self.handle, int(n_tris), C.c_void_p(geom_ptr), C.c_void_p(norm_ptr), 1 if refit else 0))
 
     def info(self):
         out = SceneInfo()

@@ -941,21 +941,25 @@ int rtc_scene_build_bvh_device(rtc_scene* scene) {
 }
 
 namespace {
-int update_triangles_impl(rtc_scene* scene, int64_t n_tris, const double* tri_geom, const double* tri_norm, bool refit);
+int update_triangles_impl(rtc_scene* scene, int64_t n_tris, const double* tri_geom, const double* tri_norm, bool refit, bool on_device);
 }
 
 int rtc_scene_update_triangles(rtc_scene* scene, int64_t n_tris, const double* tri_geom, const double* tri_norm) {
-    return update_triangles_impl(scene, n_tris, tri_geom, tri_norm, false);
+    return update_triangles_impl(scene, n_tris, tri_geom, tri_norm, false, false);
 }
 
 int rtc_scene_refit_triangles(rtc_scene* scene, int64_t n_tris, const double* tri_geom, const double* tri_norm) {
-    return update_triangles_impl(scene, n_tris, tri_geom, tri_norm, true);
+    return update_triangles_impl(scene, n_tris, tri_geom, tri_norm, true, false);
+}
+
+int rtc_scene_update_triangles_device(rtc_scene* scene, int64_t n_tris, const double* tri_geom_dev, const double* tri_norm_dev, int refit) {
+    return update_triangles_impl(scene, n_tris, tri_geom_dev, tri_norm_dev, refit != 0, true);
 }
 
 }  // extern "C"
 
 namespace {
-int update_triangles_impl(rtc_scene* scene, int64_t n_tris, const double* tri_geom, const double* tri_norm, bool refit) {
+int update_triangles_impl(rtc_scene* scene, int64_t n_tris, const double* tri_geom, const double* tri_norm, bool refit, bool on_device) {
     if (!scene || !tri_geom || !tri_norm) return fail(RTC_ERR_INVALID, "null argument");
     if (n_tris != scene->n_tris) return fail(RTC_ERR_INVALID, "scene has %lld triangles, got %lld", (long long)scene->n_tris, (long long)n_tris);
     if (n_tris == 0) return 0;
@@ -963,6 +967,13 @@ int update_triangles_impl(rtc_scene* scene, int64_t n_tris, const double* tri_ge
     std::lock_guard<std::mutex> lock(scene->ws_mutex);
     HIP_TRY(hipDeviceSynchronize());
     const size_t n = 12 * (size_t)n_tris;
+    if (on_device) {
+        hipLaunchKernelGGL(rtc::tri_rows_from_device_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, (long long)n, tri_geom, tri_norm,
+                           const_cast<double*>(scene->d64.tri_geom), const_cast<double*>(scene->d64.tri_norm),
+                           const_cast<float*>(scene->d32.tri_geom), const_cast<float*>(scene->d32.tri_norm));
+        HIP_TRY(hipGetLastError());
+        return refit ? refit_triangle_bvh_device(scene) : rebuild_triangle_bvh_device(scene);
+    }
     std::vector<float> g32 = cast_vec<float>(tri_geom, n), n32 = cast_vec<float>(tri_norm, n);
     HIP_TRY(hipMemcpy(const_cast<double*>(scene->d64.tri_geom), tri_geom, n * sizeof(double), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(const_cast<double*>(scene->d64.tri_norm), tri_norm, n * sizeof(double), hipMemcpyHostToDevice));

@@ -134,6 +134,14 @@ __global__ void lbvh_depth_kernel(int n_leaves, const int32_t* parent_inner, con
     atomicMax(deepest, d);
 }
 
+// triangle table (both precisions) refreshed from fp64 rows already on the device
+__global__ void tri_rows_from_device_kernel(long long n12, const double* geom, const double* norm, double* geom64, double* norm64, float* geom32, float* norm32) {
+    long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n12) return;
+    double g = geom[t], m = norm[t];
+    geom64[t] = g; norm64[t] = m; geom32[t] = (float)g; norm32[t] = (float)m;
+}
+
 // ---- refit: the tree keeps its shape (whichever builder made it), only the boxes follow the triangles ----
 
 // BVH-ordered rows refreshed from the triangle table: position pos holds row row_of[pos]

@@ -485,3 +485,20 @@ def test_refit_follows_a_deforming_mesh():
         sc.update_triangles(g1, cs.arrays["tri_norm"], refit=True)            # ... refitted back to g1
         d, idd = sc.render(cam, precision="fp64", want_ids=True)
         _same_image(want1, d, ids1, idd)
+        # rows handed over in device memory: same tree and rows as the host-pointer calls give, so the same frames
+        import torch
+        tg = torch.from_numpy(np.ascontiguousarray(g2)).to("cuda:0")
+        tn = torch.from_numpy(np.ascontiguousarray(cs.arrays["tri_norm"], dtype=np.float64)).to("cuda:0")
+        torch.cuda.synchronize()
+        sc.update_triangles_device(tg.data_ptr(), tn.data_ptr(), len(g2), refit=True)
+        e, ie = sc.render(cam, precision="fp64", want_ids=True)
+        e32, _ = sc.render(cam, precision="fp32")
+        sc.update_triangles(g2, cs.arrays["tri_norm"], refit=True)
+        f, _ = sc.render(cam, precision="fp64")
+        f32, _ = sc.render(cam, precision="fp32")
+        np.testing.assert_array_equal(e, f)
+        np.testing.assert_array_equal(e32, f32)
+        _same_image(want2, e, ids2, ie)
+        sc.update_triangles_device(tg.data_ptr(), tn.data_ptr(), len(g2), refit=False)
+        h, ih = sc.render(cam, precision="fp64", want_ids=True)
+        _same_image(want2, h, ids2, ih)
