@@ -71,11 +71,16 @@ class _Compiler(object):
         self.programs, self.instr = [], []
         self.textures, self._tex_of = [], {}
         self._inv_cache = {}
+        self._ident = np.eye(4)
+        self._ident_key = self._ident.tobytes()
+        self._xform_by_id = {}                       # id(matrix) -> (matrix kept alive, row)
 
     # ---- transforms ------------------------------------------------------------------
     def _inverse(self, t):
         arr = _a(t)
         key = arr.tobytes()
+        if key == self._ident_key:
+            return self._ident            # one shared object: lets shape() skip the product (a mesh's triangles)
         inv = self._inv_cache.get(key)
         if inv is None:
             inv = np.linalg.inv(arr)      # matrix.py:393
@@ -83,18 +88,22 @@ class _Compiler(object):
         return inv
 
     def _xform(self, m):
+        hit = self._xform_by_id.get(id(m))
+        if hit is not None:
+            return hit[1]
         key = m.tobytes()
         idx = self._xform_of.get(key)
         if idx is None:
             idx = self._xform_of[key] = len(self.xforms)
             self.xforms.append(m)
+        self._xform_by_id[id(m)] = (m, idx)
         return idx
 
     # ---- tree walk -------------------------------------------------------------------
     def shape(self, obj, m_parent, in_csg):
         name = type(obj).__name__
         inv = self._inverse(obj.transform)
-        m = inv if m_parent is None else inv @ m_parent
+        m = inv if m_parent is None else (m_parent if inv is self._ident else inv @ m_parent)
         if name == "Group":
             for c in list(obj.children):
                 self.shape(c, m, in_csg)
@@ -136,12 +145,14 @@ class _Compiler(object):
         if kind == K_TRIANGLE:
             self.leaf_tri.append(len(self.tri_rows))
             flat = name == "Triangle"
+            # the raw vertex (and normal) arrays; stacked in bulk by finish()
+            p1, p2, p3 = obj.p1, obj.p2, obj.p3
             if flat:
-                row = np.concatenate([_a(obj.p1, 3), _a(obj.p2, 3), _a(obj.p3, 3), np.zeros(9)])
+                self.tri_rows.append((getattr(p1, "arr", p1), getattr(p2, "arr", p2), getattr(p3, "arr", p3)))
             else:
-                row = np.concatenate([_a(obj.p1, 3), _a(obj.p2, 3), _a(obj.p3, 3),
-                                      _a(obj.n1, 3), _a(obj.n2, 3), _a(obj.n3, 3)])
-            self.tri_rows.append(row)
+                n1, n2, n3 = obj.n1, obj.n2, obj.n3
+                self.tri_rows.append((getattr(p1, "arr", p1), getattr(p2, "arr", p2), getattr(p3, "arr", p3),
+                                      getattr(n1, "arr", n1), getattr(n2, "arr", n2), getattr(n3, "arr", n3)))
             self.tri_xform.append(self.leaf_xform[-1])
             self.tri_leaf.append(leaf)
             self.tri_flat.append(flat)
@@ -276,9 +287,17 @@ class _Compiler(object):
         tri_lo = np.zeros((n_tris, 3))
         tri_hi = np.zeros((n_tris, 3))
         if n_tris:
-            rows = np.array(self.tri_rows, f64)
             txf = np.array(self.tri_xform, i32)
             flat = np.array(self.tri_flat, bool)
+            rows = np.zeros((n_tris, 18))
+            for is_flat, k in ((True, 3), (False, 6)):
+                sel = np.nonzero(flat == is_flat)[0]
+                if sel.size:
+                    try:
+                        block = np.array([self.tri_rows[i] for i in sel], f64)           # (n, k, 3 or 4)
+                    except ValueError:                                                  # mixed 3- and 4-component tuples
+                        block = np.array([[np.asarray(v, f64)[:3] for v in self.tri_rows[i]] for i in sel], f64)
+                    rows[sel, :3 * k] = block[:, :, :3].reshape(sel.size, 3 * k)
             for xi in np.unique(txf):
                 sel = np.nonzero(txf == xi)[0]
                 m = xf[xi]
@@ -301,28 +320,40 @@ class _Compiler(object):
                 tri_norm[sel] = nn
                 pts = np.stack(p, axis=0)
                 tri_lo[sel], tri_hi[sel] = pts.min(axis=0), pts.max(axis=0)
+        # world AABB per leaf as arrays (NaN = no finite box): analytic leaves from the walk, triangles in bulk
+        leaf_lo = np.full((n_leaves, 3), np.nan)
+        leaf_hi = np.full((n_leaves, 3), np.nan)
+        for leaf, (lo, hi) in enumerate(zip(self.leaf_lo, self.leaf_hi)):
+            if lo is not None:
+                leaf_lo[leaf], leaf_hi[leaf] = lo, hi
+        if n_tris:
             tl = np.array(self.tri_leaf, i32)
-            for k, leaf in enumerate(tl):
-                self.leaf_lo[leaf], self.leaf_hi[leaf] = tri_lo[k], tri_hi[k]
+            leaf_lo[tl], leaf_hi[tl] = tri_lo, tri_hi
 
         # items for the BVH / the unbounded list
         leaf_tri = np.array(self.leaf_tri, i32).reshape(-1)
-        item_prim, item_lo, item_hi, unb = [], [], [], []
-        for kind, leaf in self.items:
-            idx = int(leaf_tri[leaf]) if kind == K_TRIANGLE else leaf
-            item_prim.append(prim_code(kind, leaf_noshadow[leaf], idx))
-            item_lo.append(self.leaf_lo[leaf])
-            item_hi.append(self.leaf_hi[leaf])
-        for kind, leaf in self.unbounded:
-            unb.append(prim_code(kind, leaf_noshadow[leaf], leaf))
+
+        def codes(pairs):
+            if not pairs:
+                return np.zeros(0, i32)
+            kinds = np.array([k for k, _ in pairs], np.uint32)
+            leaves = np.array([l for _, l in pairs], np.int64)
+            idx = np.where(kinds == K_TRIANGLE, leaf_tri[leaves], leaves).astype(np.uint32)
+            return ((kinds << 28) | (leaf_noshadow[leaves].astype(np.uint32) << 27) | (idx & 0x07FFFFFF)).view(i32)
+
+        item_leaves = np.array([l for _, l in self.items], np.int64)
+        item_prim = list(codes(self.items))
+        item_lo = list(leaf_lo[item_leaves]) if len(item_leaves) else []
+        item_hi = list(leaf_hi[item_leaves]) if len(item_leaves) else []
+        unb = list(codes(self.unbounded))
         for root, (_, _, l0, l2) in enumerate(self.csg_roots):
-            los = [self.leaf_lo[l] for l in range(l0, l2)]
-            if any(b is None for b in los) or not all(np.all(np.isfinite(b)) for b in los):
+            los, his = leaf_lo[l0:l2], leaf_hi[l0:l2]
+            if not (np.all(np.isfinite(los)) and np.all(np.isfinite(his))):
                 unb.append(prim_code(K_CSG_ROOT, False, root))
             else:
                 item_prim.append(prim_code(K_CSG_ROOT, False, root))
-                item_lo.append(np.min(np.array(los), axis=0))
-                item_hi.append(np.max(np.array([self.leaf_hi[l] for l in range(l0, l2)]), axis=0))
+                item_lo.append(np.min(los, axis=0))
+                item_hi.append(np.max(his, axis=0))
         # an item with non-finite bounds (degenerate transform) is tested for every ray instead
         if item_prim:
             lo_a, hi_a = np.array(item_lo, f64).reshape(-1, 3), np.array(item_hi, f64).reshape(-1, 3)

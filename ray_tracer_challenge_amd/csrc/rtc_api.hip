@@ -9,6 +9,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/rtc_api.h"
@@ -304,6 +305,12 @@ struct rtc_scene {
     DeviceArena tbvh_mem;
     // for refits (same arena): triangle row at each BVH position, parent link of each node, arrival counters
     int32_t* d_tb_row = nullptr; int32_t* d_tparent = nullptr; uint32_t* d_tarrived = nullptr;
+    // device-side frame, hit ids, counters and tile list of the host-buffer entry points, kept between calls
+    std::mutex out_mutex;
+    double* out_rgb = nullptr; int32_t* out_id = nullptr; int64_t* out_rays = nullptr; int32_t* out_tiles = nullptr;
+    size_t out_rgb_px = 0, out_id_px = 0, out_tiles_n = 0;
+    uint8_t* out_ppm = nullptr; size_t out_ppm_bytes = 0;
+    hipEvent_t out_e0 = nullptr, out_e1 = nullptr;
     struct FbKey { rtc_camera cam; int32_t precision, depth, tile_size, n_tiles; const int32_t* tile_ids; } fb_key{};
     int fb_age = 0;
 };
@@ -847,47 +854,49 @@ int render_host(rtc_scene* scene, const rtc_camera* cam, const rtc_render_opts* 
     if (stats_out) memset(stats_out, 0, sizeof(*stats_out));
     if (n_px == 0) return 0;
     HIP_TRY(hipSetDevice(scene->device));
-    double* d_rgb = nullptr; int32_t* d_id = nullptr; int64_t* d_rays = nullptr; int32_t* d_tiles = nullptr;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    int rc = 0;
-    auto cleanup = [&]() {
-        if (d_rgb) (void)hipFree(d_rgb);
-        if (d_id) (void)hipFree(d_id);
-        if (d_rays) (void)hipFree(d_rays);
-        if (d_tiles) (void)hipFree(d_tiles);
-        if (e0) (void)hipEventDestroy(e0);
-        if (e1) (void)hipEventDestroy(e1);
+    std::lock_guard<std::mutex> out_lock(scene->out_mutex);
+    // buffers grown on demand and kept in the handle: a frame-sized hipMalloc + hipFree per call costs more than the kernel
+    auto grow = [&](auto*& ptr, size_t& have, size_t want, size_t elem) -> int {
+        if (have >= want) return 0;
+        if (ptr) { (void)hipFree(ptr); ptr = nullptr; have = 0; }
+        void* p = nullptr;
+        HIP_TRY(hipMalloc(&p, want * elem));
+        ptr = static_cast<std::remove_reference_t<decltype(ptr)>>(p); have = want;
+        return 0;
     };
-#define TRY_C(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { rc = fail(RTC_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); cleanup(); return rc; } } while (0)
-    TRY_C(hipMalloc(&d_rgb, n_px * 3 * sizeof(double)));
-    if (tiled) TRY_C(hipMemset(d_rgb, 0, n_px * 3 * sizeof(double)));
-    if (hit_id_out) { TRY_C(hipMalloc(&d_id, n_px * sizeof(int32_t))); TRY_C(hipMemset(d_id, 0xFF, n_px * sizeof(int32_t))); }
+    if (int rc = grow(scene->out_rgb, scene->out_rgb_px, n_px, 3 * sizeof(double))) return rc;
+    if (hit_id_out) if (int rc = grow(scene->out_id, scene->out_id_px, n_px, sizeof(int32_t))) return rc;
+    if (tiled) if (int rc = grow(scene->out_tiles, scene->out_tiles_n, (size_t)n_tiles, sizeof(int32_t))) return rc;
+    if (!scene->out_rays) HIP_TRY(hipMalloc((void**)&scene->out_rays, 13 * sizeof(int64_t)));
+    if (!scene->out_e0) HIP_TRY(hipEventCreate(&scene->out_e0));
+    if (!scene->out_e1) HIP_TRY(hipEventCreate(&scene->out_e1));
+    double* d_rgb = scene->out_rgb; int32_t* d_id = hit_id_out ? scene->out_id : nullptr; int64_t* d_rays = scene->out_rays;
+    int32_t* d_tiles = tiled ? scene->out_tiles : nullptr;
+    hipEvent_t e0 = scene->out_e0, e1 = scene->out_e1;
+    int rc = 0;
+#define TRY_C(expr) HIP_TRY(expr)
+    if (tiled) TRY_C(hipMemsetAsync(d_rgb, 0, n_px * 3 * sizeof(double), nullptr));
+    if (hit_id_out) TRY_C(hipMemsetAsync(d_id, 0xFF, n_px * sizeof(int32_t), nullptr));
     const bool want_work = stats_out && opts && (opts->flags & RTC_FLAG_COUNT_WORK);
-    TRY_C(hipMalloc(&d_rays, 13 * sizeof(int64_t)));
-    TRY_C(hipMemset(d_rays, 0, 13 * sizeof(int64_t)));
-    if (tiled) {
-        TRY_C(hipMalloc(&d_tiles, (size_t)n_tiles * sizeof(int32_t)));
-        TRY_C(hipMemcpy(d_tiles, tile_ids, (size_t)n_tiles * sizeof(int32_t), hipMemcpyHostToDevice));
-    }
-    TRY_C(hipEventCreate(&e0));
-    TRY_C(hipEventCreate(&e1));
+    TRY_C(hipMemsetAsync(d_rays, 0, 13 * sizeof(int64_t), nullptr));
+    if (tiled) TRY_C(hipMemcpy(d_tiles, tile_ids, (size_t)n_tiles * sizeof(int32_t), hipMemcpyHostToDevice));
     TRY_C(hipEventRecord(e0, nullptr));
     rc = launch(scene, cam, opts, n_tiles, d_tiles, d_rgb, d_id, d_rays, want_work ? d_rays + 4 : nullptr, nullptr);
-    if (rc) { cleanup(); return rc; }
+    if (rc) return rc;
     TRY_C(hipEventRecord(e1, nullptr));
-    TRY_C(hipEventSynchronize(e1));
-    float ms = 0;
-    TRY_C(hipEventElapsedTime(&ms, e0, e1));
-    TRY_C(hipMemcpy(rgb_out, d_rgb, n_px * 3 * sizeof(double), hipMemcpyDeviceToHost));
+    TRY_C(hipMemcpy(rgb_out, d_rgb, n_px * 3 * sizeof(double), hipMemcpyDeviceToHost));     // null stream: after the kernel
     if (hit_id_out) TRY_C(hipMemcpy(hit_id_out, d_id, n_px * sizeof(int32_t), hipMemcpyDeviceToHost));
     if (stats_out) {
-        TRY_C(hipMemcpy(stats_out->rays, d_rays, 4 * sizeof(int64_t), hipMemcpyDeviceToHost));
-        if (want_work) TRY_C(hipMemcpy(stats_out->work, d_rays + 4, 8 * sizeof(int64_t), hipMemcpyDeviceToHost));
-        TRY_C(hipMemcpy(&stats_out->shadow_rays_culled, d_rays + 12, sizeof(int64_t), hipMemcpyDeviceToHost));
+        int64_t host_rays[13];
+        TRY_C(hipMemcpy(host_rays, d_rays, sizeof(host_rays), hipMemcpyDeviceToHost));
+        float ms = 0;
+        TRY_C(hipEventElapsedTime(&ms, e0, e1));
+        memcpy(stats_out->rays, host_rays, 4 * sizeof(int64_t));
+        if (want_work) memcpy(stats_out->work, host_rays + 4, 8 * sizeof(int64_t));
+        stats_out->shadow_rays_culled = host_rays[12];
         stats_out->kernel_ms = ms;
     }
 #undef TRY_C
-    cleanup();
     return 0;
 }
 
@@ -896,6 +905,17 @@ int render_host(rtc_scene* scene, const rtc_camera* cam, const rtc_render_opts* 
 extern "C" {
 
 int rtc_version(void) { return RTC_VERSION; }
+
+int rtc_host_alloc(size_t bytes, void** out) {
+    if (!out) return fail(RTC_ERR_INVALID, "null argument");
+    *out = nullptr;
+    HIP_TRY(hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault));
+    return 0;
+}
+
+void rtc_host_free(void* ptr) {
+    if (ptr) (void)hipHostFree(ptr);
+}
 
 int rtc_device_count(void) {
     int n = 0;
@@ -927,6 +947,13 @@ void rtc_scene_destroy(rtc_scene* scene) {
     (void)hipSetDevice(scene->device);
     scene->shared.release(); scene->mem64.release(); scene->mem32.release();
     scene->fb_mem.release(); scene->lv_mem.release(); scene->tbvh_mem.release();
+    if (scene->out_rgb) (void)hipFree(scene->out_rgb);
+    if (scene->out_id) (void)hipFree(scene->out_id);
+    if (scene->out_ppm) (void)hipFree(scene->out_ppm);
+    if (scene->out_rays) (void)hipFree(scene->out_rays);
+    if (scene->out_tiles) (void)hipFree(scene->out_tiles);
+    if (scene->out_e0) (void)hipEventDestroy(scene->out_e0);
+    if (scene->out_e1) (void)hipEventDestroy(scene->out_e1);
     if (scene->fb_used_host) (void)hipHostFree(scene->fb_used_host);
     if (scene->fb_used_event) (void)hipEventDestroy(scene->fb_used_event);
     delete scene;
@@ -1057,32 +1084,37 @@ int rtc_render_ppm(rtc_scene* scene, const rtc_camera* cam, const rtc_render_opt
     if ((clamped_out || scaled_out) && capacity < (int64_t)total) return fail(RTC_ERR_INVALID, "ppm buffer too small: %lld < %zu", (long long)capacity, total);
     if (stats_out) memset(stats_out, 0, sizeof(*stats_out));
     HIP_TRY(hipSetDevice(scene->device));
-    double* d_rgb = nullptr; double* d_max = nullptr; uint8_t* d_out = nullptr; int64_t* d_rays = nullptr;
+    std::lock_guard<std::mutex> out_lock(scene->out_mutex);
+    // frame, counters, the maximum and the encoded file stay in the handle between calls (see render_host)
+    if (scene->out_rgb_px < n_px) {
+        if (scene->out_rgb) { (void)hipFree(scene->out_rgb); scene->out_rgb = nullptr; scene->out_rgb_px = 0; }
+        HIP_TRY(hipMalloc((void**)&scene->out_rgb, body * sizeof(double)));
+        scene->out_rgb_px = n_px;
+    }
+    if (scene->out_ppm_bytes < total + sizeof(double)) {
+        if (scene->out_ppm) { (void)hipFree(scene->out_ppm); scene->out_ppm = nullptr; scene->out_ppm_bytes = 0; }
+        HIP_TRY(hipMalloc((void**)&scene->out_ppm, total + 2 * sizeof(double)));
+        scene->out_ppm_bytes = total + sizeof(double);
+    }
+    if (!scene->out_rays) HIP_TRY(hipMalloc((void**)&scene->out_rays, 13 * sizeof(int64_t)));
+    double* d_rgb = scene->out_rgb; int64_t* d_rays = scene->out_rays;
+    double* d_max = reinterpret_cast<double*>(scene->out_ppm);             // 8 bytes in front of the file
+    uint8_t* d_out = scene->out_ppm + sizeof(double);
     int rc = 0;
-    auto cleanup = [&]() {
-        if (d_rgb) (void)hipFree(d_rgb);
-        if (d_max) (void)hipFree(d_max);
-        if (d_out) (void)hipFree(d_out);
-        if (d_rays) (void)hipFree(d_rays);
-    };
-#define TRY_C(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { rc = fail(RTC_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); cleanup(); return rc; } } while (0)
-    TRY_C(hipMalloc(&d_rgb, body * sizeof(double)));
-    TRY_C(hipMalloc(&d_max, sizeof(double)));
-    TRY_C(hipMalloc(&d_out, total));
-    TRY_C(hipMalloc(&d_rays, 13 * sizeof(int64_t)));
-    TRY_C(hipMemset(d_rays, 0, 13 * sizeof(int64_t)));
+#define TRY_C(expr) HIP_TRY(expr)
+    TRY_C(hipMemsetAsync(d_rays, 0, 13 * sizeof(int64_t), nullptr));
     const bool want_work = stats_out && opts && (opts->flags & RTC_FLAG_COUNT_WORK);
     rc = launch(scene, cam, opts, 0, nullptr, d_rgb, nullptr, d_rays, want_work ? d_rays + 4 : nullptr, nullptr);
-    if (rc) { cleanup(); return rc; }
+    if (rc) return rc;
     TRY_C(hipMemcpy(d_out, header, (size_t)hlen, hipMemcpyHostToDevice));
     const uint8_t newline = 10;
     TRY_C(hipMemcpy(d_out + hlen + body, &newline, 1, hipMemcpyHostToDevice));
     for (int variant = 0; variant < 2; variant++) {
         uint8_t* dst = variant == 0 ? clamped_out : scaled_out;
         if (!dst) continue;
-        if (variant == 1) { rc = rtc_frame_max_device(d_rgb, (int64_t)body, d_max, nullptr); if (rc) { cleanup(); return rc; } }
+        if (variant == 1) { rc = rtc_frame_max_device(d_rgb, (int64_t)body, d_max, nullptr); if (rc) return rc; }
         rc = rtc_ppm_body_device(d_rgb, cam->hsize, cam->vsize, variant == 1 ? d_max : nullptr, d_out + hlen, nullptr);
-        if (rc) { cleanup(); return rc; }
+        if (rc) return rc;
         TRY_C(hipMemcpy(dst, d_out, total, hipMemcpyDeviceToHost));
     }
     if (stats_out) {
@@ -1091,7 +1123,6 @@ int rtc_render_ppm(rtc_scene* scene, const rtc_camera* cam, const rtc_render_opt
         TRY_C(hipMemcpy(&stats_out->shadow_rays_culled, d_rays + 12, sizeof(int64_t), hipMemcpyDeviceToHost));
     }
 #undef TRY_C
-    cleanup();
     return 0;
 }
 
