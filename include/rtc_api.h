@@ -42,13 +42,19 @@ enum { RTC_CSG_UNION = 0, RTC_CSG_INTERSECT = 1, RTC_CSG_DIFFERENCE = 2 };
 /* pattern node types (shapes.py:1501-2033) */
 enum { RTC_PAT_TEST = 0, RTC_PAT_CHECKERS = 1, RTC_PAT_GRADIENT = 2, RTC_PAT_RADIAL = 3,
        RTC_PAT_RING = 4, RTC_PAT_STRIPE = 5,
+       RTC_PAT_PERTURBED = 8, /* only named by RTC_OP_PERTURB; pat_param = frequency, scale factor, octaves */
        RTC_PAT_MAP_PLANAR = 9, RTC_PAT_MAP_SPHERICAL = 10, RTC_PAT_MAP_CYLINDRICAL = 11,
        RTC_PAT_MAP_CUBE = 12, RTC_UV_CHECKER = 20, RTC_UV_ALIGN = 21, RTC_UV_IMAGE = 22 };
 /* pattern program opcodes: a material's pattern is a postfix program over a colour stack.
  * EVAL pushes node(point); EVAL_AB pops b then a and pushes node(point) evaluated with those
  * two colours (NestedPattern, shapes.py:1892-1895); BLEND pops two and pushes their mean
- * (BlendedPattern, shapes.py:1874-1877). */
-enum { RTC_OP_EVAL = 0, RTC_OP_EVAL_AB = 1, RTC_OP_BLEND = 2 };
+ * (BlendedPattern, shapes.py:1874-1877).  PERTURB replaces the world point every later EVAL
+ * sees by the point moved with Perlin noise (PerturbedPattern._perturb, shapes.py:1911-1922:
+ * node = an RTC_PAT_PERTURBED record), RESTORE brings the previous point back; they bracket the
+ * program of the wrapped pattern and nest at most RTC_PERTURB_DEPTH (2) deep.  The noise is
+ * pnoise3 of the PyPI `noise` package restated from its published algorithm -- that package is in
+ * neither the reference tree nor this image: parity unpinned. */
+enum { RTC_OP_EVAL = 0, RTC_OP_EVAL_AB = 1, RTC_OP_BLEND = 2, RTC_OP_PERTURB = 3, RTC_OP_RESTORE = 4 };
 
 /* A "prim code" names something a ray can be tested against:
  *   bits 31..28 kind, bit 27 = does NOT cast shadows, bits 26..0 index

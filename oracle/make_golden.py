@@ -125,6 +125,9 @@ def main(which):
         "shadow_glamour_shot_nojitter": lambda: make("shadow_glamour_shot_nojitter", "shadow_glamour_shot/shadow_glamour_shot.yml", REF,
                                                      (150, 60), "all", edit=lambda t: t.replace("jitter: true", "jitter: false")),
         "teapot": lambda: make("teapot", "obj_file_test/obj_file_test.yml", objs_cwd, None, 8, divide=1),
+        # this repository's own scene (scenes/src/perturbed.yml) through the reference's PerturbedPattern, with
+        # oracle/_stubs/noise.py standing in for the absent PyPI `noise`: pins the pattern's wiring, NOT the noise function
+        "perturbed": lambda: make("perturbed", os.path.join(ROOT, "scenes", "src", "perturbed.yml"), ROOT, None, "all"),
     }
 
     def skybox():

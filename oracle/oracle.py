@@ -49,7 +49,14 @@ def lib():
             build()
         _lib = C.CDLL(_LIB_PATH)
         _lib.orc_render_pixels.restype = C.c_int
+        _lib.orc_pnoise3.restype = C.c_double
+        _lib.orc_pnoise3.argtypes = [C.c_double, C.c_double, C.c_double, C.c_int]
     return _lib
+
+
+def pnoise3(x, y, z, octaves=1):
+    """noise.pnoise3 as the reference calls it (shapes.py:1916), restated in rtc_oracle.c -- parity unpinned."""
+    return float(lib().orc_pnoise3(float(x), float(y), float(z), int(octaves)))
 
 
 def _ptr(a):

@@ -362,6 +362,62 @@ static v3 normal_at(const orc_scene *s, int node, v3 world_point, double hu, dou
     return normalize(world_normal);
 }
 
+/* ---------------------------------------------------------------- pnoise3 of PyPI `noise` 1.2.2
+ * The package is a dependency of the reference (shapes.py:1496, called at :1916-1920) that is neither vendored in
+ * /root/reference nor installed in this image, so what follows restates its published algorithm: Ken Perlin's
+ * "improved noise" (2002) as packaged by Casey Duncan (_perlin.c / _noise.h) -- single-precision arithmetic,
+ * Perlin's reference permutation, a 16-entry gradient table, fade 6t^5 - 15t^4 + 10t^3, and for octaves > 1 the sum of
+ * octaves (persistence 0.5, lacunarity 2, repeat 1024 scaled per octave, base 0) divided by the sum of amplitudes.
+ * PARITY UNPINNED: no file of the reference holds an output of this function; tests/ check the restatement only
+ * against the algorithm's own invariants and against a second, independent transcription (oracle/_stubs/noise.py). */
+static const unsigned char PN_PERM[256] = {
+    151, 160, 137, 91, 90, 15, 131, 13, 201, 95, 96, 53, 194, 233, 7, 225, 140, 36, 103, 30, 69, 142, 8, 99, 37, 240, 21, 10, 23,
+    190, 6, 148, 247, 120, 234, 75, 0, 26, 197, 62, 94, 252, 219, 203, 117, 35, 11, 32, 57, 177, 33, 88, 237, 149, 56, 87, 174,
+    20, 125, 136, 171, 168, 68, 175, 74, 165, 71, 134, 139, 48, 27, 166, 77, 146, 158, 231, 83, 111, 229, 122, 60, 211, 133,
+    230, 220, 105, 92, 41, 55, 46, 245, 40, 244, 102, 143, 54, 65, 25, 63, 161, 1, 216, 80, 73, 209, 76, 132, 187, 208, 89, 18,
+    169, 200, 196, 135, 130, 116, 188, 159, 86, 164, 100, 109, 198, 173, 186, 3, 64, 52, 217, 226, 250, 124, 123, 5, 202, 38,
+    147, 118, 126, 255, 82, 85, 212, 207, 206, 59, 227, 47, 16, 58, 17, 182, 189, 28, 42, 223, 183, 170, 213, 119, 248, 152, 2,
+    44, 154, 163, 70, 221, 153, 101, 155, 167, 43, 172, 9, 129, 22, 39, 253, 19, 98, 108, 110, 79, 113, 224, 232, 178, 185, 112,
+    104, 218, 246, 97, 228, 251, 34, 242, 193, 238, 210, 144, 12, 191, 179, 162, 241, 81, 51, 145, 235, 249, 14, 239, 107, 49,
+    192, 214, 31, 181, 199, 106, 157, 184, 84, 204, 176, 115, 121, 50, 45, 127, 4, 150, 254, 138, 236, 205, 93, 222, 114, 67, 29,
+    24, 72, 243, 141, 128, 195, 78, 66, 215, 61, 156, 180};
+static const float PN_GRAD3[16][3] = {{1, 1, 0}, {-1, 1, 0}, {1, -1, 0}, {-1, -1, 0}, {1, 0, 1}, {-1, 0, 1}, {1, 0, -1}, {-1, 0, -1},
+                                      {0, 1, 1}, {0, -1, 1}, {0, 1, -1}, {0, -1, -1}, {1, 0, -1}, {-1, 0, -1}, {0, -1, 1}, {0, 1, 1}};
+static int pn_perm(int i) { return PN_PERM[i & 255]; } /* the package doubles the table; indices here stay below 512 */
+static float pn_grad3(int hash, float x, float y, float z) {
+    const float *g = PN_GRAD3[hash & 15];
+    return x * g[0] + y * g[1] + z * g[2];
+}
+static float pn_lerp(float t, float a, float b) { return a + t * (b - a); }
+static float pn_noise3(float x, float y, float z, int repeatx, int repeaty, int repeatz, int base) {
+    int i = (int)floorf(fmodf(x, (float)repeatx)), j = (int)floorf(fmodf(y, (float)repeaty)), k = (int)floorf(fmodf(z, (float)repeatz));
+    int ii = (int)fmodf((float)(i + 1), (float)repeatx), jj = (int)fmodf((float)(j + 1), (float)repeaty), kk = (int)fmodf((float)(k + 1), (float)repeatz);
+    i = (i & 255) + base; j = (j & 255) + base; k = (k & 255) + base;
+    ii = (ii & 255) + base; jj = (jj & 255) + base; kk = (kk & 255) + base;
+    x -= floorf(x); y -= floorf(y); z -= floorf(z);
+    float fx = x * x * x * (x * (x * 6 - 15) + 10), fy = y * y * y * (y * (y * 6 - 15) + 10), fz = z * z * z * (z * (z * 6 - 15) + 10);
+    int A = pn_perm(i), AA = pn_perm(A + j), AB = pn_perm(A + jj), B = pn_perm(ii), BA = pn_perm(B + j), BB = pn_perm(B + jj);
+    return pn_lerp(fz,
+                   pn_lerp(fy, pn_lerp(fx, pn_grad3(pn_perm(AA + k), x, y, z), pn_grad3(pn_perm(BA + k), x - 1, y, z)),
+                           pn_lerp(fx, pn_grad3(pn_perm(AB + k), x, y - 1, z), pn_grad3(pn_perm(BB + k), x - 1, y - 1, z))),
+                   pn_lerp(fy, pn_lerp(fx, pn_grad3(pn_perm(AA + kk), x, y, z - 1), pn_grad3(pn_perm(BA + kk), x - 1, y, z - 1)),
+                           pn_lerp(fx, pn_grad3(pn_perm(AB + kk), x, y - 1, z - 1), pn_grad3(pn_perm(BB + kk), x - 1, y - 1, z - 1))));
+}
+/* noise.pnoise3(x, y, z, octaves): arguments narrowed to float on entry, the float result widened on return */
+double orc_pnoise3(double xd, double yd, double zd, int octaves) {
+    float x = (float)xd, y = (float)yd, z = (float)zd;
+    if (octaves == 1) return (double)pn_noise3(x, y, z, 1024, 1024, 1024, 0);
+    if (octaves < 1) return NAN; /* the package raises ValueError */
+    float freq = 1.0f, amp = 1.0f, max = 0.0f, total = 0.0f;
+    for (int o = 0; o < octaves; o++) {
+        total += pn_noise3(x * freq, y * freq, z * freq, (int)(1024 * freq), (int)(1024 * freq), (int)(1024 * freq), 0) * amp;
+        max += amp;
+        freq *= 2.0f;
+        amp *= 0.5f;
+    }
+    return (double)(total / max);
+}
+
 /* ---------------------------------------------------------------- patterns */
 typedef struct { double r, g, b; } rgb_t;
 static rgb_t RGB(double r, double g, double b) { rgb_t c = {r, g, b}; return c; }
@@ -464,7 +520,7 @@ static rgb_t pattern_at(ctx_t *c, int p, v3 pt) {
         return uv_pattern_at(c, ch[face], u, v);
     }
     }
-    return RGB(NAN, NAN, NAN); /* perturbed: parity unpinned (needs PyPI `noise`), not restated */
+    return RGB(NAN, NAN, NAN);
 }
 
 /* Pattern.pattern_at_shape (shapes.py:1664-1666) and its three overrides (1874-1877, 1892-1895) */
@@ -484,6 +540,18 @@ static rgb_t pattern_at_shape(ctx_t *c, int p, int node, v3 world_pt) {
         rgb_t b = pattern_at_shape(c, ch[2], node, world_pt);
         q[3] = b.r; q[4] = b.g; q[5] = b.b;
         return pattern_at_shape(c, ch[0], node, world_pt);
+    }
+    case ORC_PAT_PERTURBED: { /* shapes.py:1911-1925: the WORLD point is moved, then handed to p1.pattern_at_shape */
+        const double *q = s->pat_param + 4 * p;
+        double freq = q[0], scale = q[1];
+        int octaves = (int)q[2];
+        double x = world_pt.x / freq, y = world_pt.y / freq, z = world_pt.z / freq;
+        double new_x = world_pt.x + orc_pnoise3(x, y, z, octaves) * scale;
+        z += 1.0;
+        double new_y = world_pt.y + orc_pnoise3(x, y, z, octaves) * scale;
+        z += 1.0;
+        double new_z = world_pt.z + orc_pnoise3(x, y, z, octaves) * scale;
+        return pattern_at_shape(c, ch[0], node, V(new_x, new_y, new_z));
     }
     default: {
         v3 object_point = world_to_object(s, node, world_pt);

@@ -95,6 +95,8 @@ int orc_intersect_node(const orc_scene *s, int node, const double *o3, const dou
                        double *t_out, int32_t *node_out);
 void orc_color_at(const orc_scene *s, const double *o3, const double *d3, int remaining, double *rgb);
 void orc_normal_at(const orc_scene *s, int node, const double *p3, double u, double v, double *n3);
+/* pnoise3 of the PyPI `noise` package as the reference calls it (shapes.py:1916); restated, parity unpinned */
+double orc_pnoise3(double x, double y, double z, int octaves);
 void orc_pattern_at_shape(const orc_scene *s, int pattern, int node, const double *p3, double *rgb);
 void orc_lighting(const orc_scene *s, int material, int node, int light, const double *p3,
                   const double *eye3, const double *n3, double intensity, double *rgb);

@@ -30,7 +30,8 @@ _PAT_SIMPLE = {"Pattern": 0, "Checkers": 1, "Gradient": 2, "RadialGradient": 3, 
 _TWO_COLOR = ("Checkers", "Gradient", "RadialGradient", "Ring", "Stripe")
 _UV = {"UVChecker": 20, "UVAlignCheck": 21, "UVTexturePattern": 22}
 _UVMAP = {"PlaneUVMap": 9, "SphereUVMap": 10}
-OP_EVAL, OP_EVAL_AB, OP_BLEND = 0, 1, 2
+OP_EVAL, OP_EVAL_AB, OP_BLEND, OP_PERTURB, OP_RESTORE = 0, 1, 2, 3, 4
+PAT_PERTURBED = 8
 _MAX_HITS = {K_SPHERE: 2, K_PLANE: 1, K_CUBE: 2, K_CYLINDER: 4, K_CONE: 4, K_TRIANGLE: 1}
 
 
@@ -221,9 +222,13 @@ class _Compiler(object):
             else:
                 # the colours written into p1.a / p1.b are never read by this kind of primary
                 self._emit(p.p1, code)
-        elif name == "PerturbedPattern":
-            raise NotImplementedError("PerturbedPattern needs the PyPI `noise` package's pnoise3 "
-                                      "(parity unpinned, SURVEY.md 8c); not in the compiled path")
+        elif name == "PerturbedPattern":                 # shapes.py:1911-1925 (noise: parity unpinned)
+            if not (float(p.freq) != 0.0 and int(p.octaves) == p.octaves and 1 <= int(p.octaves) <= 16):
+                raise ValueError("PerturbedPattern: frequency must not be 0 and octaves must be an integer in 1..16 "
+                                 "(noise.pnoise3 raises for octaves < 1)")
+            code.append((OP_PERTURB, self._pat_node(p)))
+            self._emit(p.p1, code)
+            code.append((OP_RESTORE, 0))
         else:
             code.append((OP_EVAL, self._pat_node(p)))
 
@@ -238,6 +243,9 @@ class _Compiler(object):
         self.pat_nodes.append(rec)
         if name in _PAT_SIMPLE:
             rec["type"] = _PAT_SIMPLE[name]
+        elif name == "PerturbedPattern":
+            rec["type"] = PAT_PERTURBED
+            rec["param"][:3] = [float(p.freq), float(p.scale_factor), float(int(p.octaves))]
         elif name in _UV:
             rec["type"] = _UV[name]
             if name == "UVChecker":

@@ -397,9 +397,22 @@ int validate(const rtc_scene_desc& d) {
     for (int i = 0; i < d.n_programs; i++) {
         if (d.prog_off[i] < 0 || d.prog_len[i] < 1 || d.prog_off[i] + d.prog_len[i] > d.n_instr)
             return fail(RTC_ERR_INVALID, "pattern program %d out of range", i);
-        int sp = 0, peak = 0;
+        int sp = 0, peak = 0, moved = 0;
         for (int k = d.prog_off[i]; k < d.prog_off[i] + d.prog_len[i]; k++) {
             int op = d.instr[2 * k], node = d.instr[2 * k + 1];
+            if (op == RTC_OP_PERTURB) {
+                if (node < 0 || node >= d.n_pat_nodes || d.pat_type[node] != RTC_PAT_PERTURBED)
+                    return fail(RTC_ERR_INVALID, "pattern program %d: PERTURB needs a perturbed-pattern node", i);
+                const double* q = d.pat_param + 4 * (size_t)node;
+                if (!(q[0] != 0.0) || !(q[2] >= 1.0 && q[2] <= 16.0) || q[2] != std::floor(q[2]))
+                    return fail(RTC_ERR_INVALID, "pattern node %d: frequency must not be 0, octaves must be 1..16", node);
+                if (++moved > RTC_PERTURB_DEPTH) return fail(RTC_ERR_LIMIT, "pattern program %d nests perturbed patterns deeper than %d", i, RTC_PERTURB_DEPTH);
+                continue;
+            }
+            if (op == RTC_OP_RESTORE) {
+                if (--moved < 0) return fail(RTC_ERR_INVALID, "pattern program %d: RESTORE without PERTURB", i);
+                continue;
+            }
             if (op == RTC_OP_BLEND) { sp -= 1; }
             else if (op == RTC_OP_EVAL || op == RTC_OP_EVAL_AB) {
                 if (node < 0 || node >= d.n_pat_nodes) return fail(RTC_ERR_INVALID, "pattern program %d: node out of range", i);
@@ -421,6 +434,7 @@ int validate(const rtc_scene_desc& d) {
             peak = std::max(peak, sp);
         }
         if (sp != 1) return fail(RTC_ERR_INVALID, "pattern program %d leaves %d values", i, sp);
+        if (moved != 0) return fail(RTC_ERR_INVALID, "pattern program %d: PERTURB without RESTORE", i);
         if (peak > RTC_PAT_STACK) return fail(RTC_ERR_LIMIT, "pattern program %d needs a stack of %d, limit %d", i, peak, RTC_PAT_STACK);
     }
     for (int i = 0; i < d.n_textures; i++)
@@ -569,6 +583,8 @@ int create_impl(const rtc_scene_desc& d, rtc_scene* sc) {
         (sc->d64.n_tnodes > 0 && (!sc->d64.tnodes || !sc->d64.tb_geom || !sc->d64.tb_leaf || !sc->d32.tnodes || !sc->d32.tb_geom)))
         return fail(RTC_ERR_HIP, "internal: BVH arrays missing on the device");
     sc->has_csg = d.n_csg_roots > 0;
+    for (int i = 0; i < d.n_instr; i++)
+        if (d.instr[2 * (size_t)i] == RTC_OP_PERTURB) sc->has_csg = true;      // the noise code lives in the same kernel variants
     for (int i = 0; i < d.n_materials; i++)
         if (d.mat[10 * (size_t)i + 7] != 0.0 || d.mat[10 * (size_t)i + 8] != 0.0) sc->has_secondary = true;
     for (int i = 0; i < d.n_lights; i++) {

@@ -33,6 +33,7 @@
 #define RTC_MAX_CSG_HITS 32   // hits gathered per CSG root per ray
 #define RTC_MAX_BOUNCE_STACK 8
 #define RTC_PAT_STACK 6
+#define RTC_PERTURB_DEPTH 2
 #define RTC_EMPTY_CHILD INT32_MIN
 
 namespace rtc {
@@ -180,7 +181,8 @@ __device__ __forceinline__ long long wave_unit(const DFrame& F, bool& lane_on) {
 // hits, light samples shaded, container passes, pattern-node evaluations.
 enum { W_NODE = 0, W_TRI = 1, W_LEAF = 2, W_CSG = 3, W_SHADE = 4, W_LIGHT = 5, W_CONTAINER = 6, W_PATTERN = 7, W_COUNT = 8 };
 // CSG = false compiles the CSG branches out of every visitor (scenes without CSG objects then
-// carry none of its per-lane hit lists).
+// carry none of its per-lane hit lists) and the Perlin noise of perturbed patterns out of the pattern
+// interpreter: the host picks the CSG = true variants for scenes that have either.
 template <bool PROF, bool CSG = true> struct Counters {
     static constexpr bool kCsg = CSG;
     unsigned int c[5];         // primary, shadow, reflection, refraction rays traced; shadow rays not traced (light behind the surface)
@@ -689,17 +691,104 @@ template <class R> __device__ __forceinline__ V3<R> pattern_at(const DScene<R>& 
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// PerturbedPattern (shapes.py:1898-1925): noise.pnoise3 of the PyPI `noise` package, which is in neither the
+// reference tree nor this image -- Ken Perlin's improved noise as that package publishes it, restated: float
+// arithmetic whatever R is (the package narrows its arguments to float), no contraction (an x86 build of it has
+// none), reference permutation, 16 gradients, octaves with persistence 0.5 / lacunarity 2 over the sum of
+// amplitudes.  PARITY UNPINNED: checked against oracle/'s restatement of the same text only.
+// ------------------------------------------------------------------------------------------
+static __device__ const unsigned char PN_PERM[256] = {
+    151, 160, 137, 91, 90, 15, 131, 13, 201, 95, 96, 53, 194, 233, 7, 225, 140, 36, 103, 30, 69, 142, 8, 99, 37, 240, 21, 10, 23,
+    190, 6, 148, 247, 120, 234, 75, 0, 26, 197, 62, 94, 252, 219, 203, 117, 35, 11, 32, 57, 177, 33, 88, 237, 149, 56, 87, 174,
+    20, 125, 136, 171, 168, 68, 175, 74, 165, 71, 134, 139, 48, 27, 166, 77, 146, 158, 231, 83, 111, 229, 122, 60, 211, 133,
+    230, 220, 105, 92, 41, 55, 46, 245, 40, 244, 102, 143, 54, 65, 25, 63, 161, 1, 216, 80, 73, 209, 76, 132, 187, 208, 89, 18,
+    169, 200, 196, 135, 130, 116, 188, 159, 86, 164, 100, 109, 198, 173, 186, 3, 64, 52, 217, 226, 250, 124, 123, 5, 202, 38,
+    147, 118, 126, 255, 82, 85, 212, 207, 206, 59, 227, 47, 16, 58, 17, 182, 189, 28, 42, 223, 183, 170, 213, 119, 248, 152, 2,
+    44, 154, 163, 70, 221, 153, 101, 155, 167, 43, 172, 9, 129, 22, 39, 253, 19, 98, 108, 110, 79, 113, 224, 232, 178, 185, 112,
+    104, 218, 246, 97, 228, 251, 34, 242, 193, 238, 210, 144, 12, 191, 179, 162, 241, 81, 51, 145, 235, 249, 14, 239, 107, 49,
+    192, 214, 31, 181, 199, 106, 157, 184, 84, 204, 176, 115, 121, 50, 45, 127, 4, 150, 254, 138, 236, 205, 93, 222, 114, 67, 29,
+    24, 72, 243, 141, 128, 195, 78, 66, 215, 61, 156, 180};
+// gradient h & 15 as three signed selectors packed two bits each (0 -> 0, 1 -> +1, 2 -> -1): x | y << 2 | z << 4
+static __device__ const unsigned char PN_GRAD[16] = {0x05, 0x06, 0x09, 0x0A, 0x11, 0x12, 0x21, 0x22, 0x14, 0x18, 0x24, 0x28, 0x21, 0x22, 0x18, 0x14};
+
+__device__ __forceinline__ int pn_perm(int i) { return PN_PERM[i & 255]; }
+__device__ __forceinline__ float pn_grad3(int hash, float x, float y, float z) {
+#pragma clang fp contract(off)
+    const int g = PN_GRAD[hash & 15];
+    const int gx = g & 3, gy = (g >> 2) & 3, gz = (g >> 4) & 3;
+    const float cx = gx == 0 ? 0.0f : (gx == 1 ? 1.0f : -1.0f), cy = gy == 0 ? 0.0f : (gy == 1 ? 1.0f : -1.0f), cz = gz == 0 ? 0.0f : (gz == 1 ? 1.0f : -1.0f);
+    return x * cx + y * cy + z * cz;
+}
+__device__ __forceinline__ float pn_lerp(float t, float a, float b) {
+#pragma clang fp contract(off)
+    return a + t * (b - a);
+}
+__device__ inline float pn_noise3(float x, float y, float z, int repeat) {
+#pragma clang fp contract(off)
+    const float rep = (float)repeat;
+    int i = (int)floorf(fmodf(x, rep)), j = (int)floorf(fmodf(y, rep)), k = (int)floorf(fmodf(z, rep));
+    int ii = (int)fmodf((float)(i + 1), rep), jj = (int)fmodf((float)(j + 1), rep), kk = (int)fmodf((float)(k + 1), rep);
+    i &= 255; j &= 255; k &= 255; ii &= 255; jj &= 255; kk &= 255;
+    x -= floorf(x); y -= floorf(y); z -= floorf(z);
+    const float fx = x * x * x * (x * (x * 6 - 15) + 10), fy = y * y * y * (y * (y * 6 - 15) + 10), fz = z * z * z * (z * (z * 6 - 15) + 10);
+    const int A = pn_perm(i), AA = pn_perm(A + j), AB = pn_perm(A + jj), B = pn_perm(ii), BA = pn_perm(B + j), BB = pn_perm(B + jj);
+    return pn_lerp(fz,
+                   pn_lerp(fy, pn_lerp(fx, pn_grad3(pn_perm(AA + k), x, y, z), pn_grad3(pn_perm(BA + k), x - 1, y, z)),
+                           pn_lerp(fx, pn_grad3(pn_perm(AB + k), x, y - 1, z), pn_grad3(pn_perm(BB + k), x - 1, y - 1, z))),
+                   pn_lerp(fy, pn_lerp(fx, pn_grad3(pn_perm(AA + kk), x, y, z - 1), pn_grad3(pn_perm(BA + kk), x - 1, y, z - 1)),
+                           pn_lerp(fx, pn_grad3(pn_perm(AB + kk), x, y - 1, z - 1), pn_grad3(pn_perm(BB + kk), x - 1, y - 1, z - 1))));
+}
+__device__ inline float pn_pnoise3(float x, float y, float z, int octaves) {
+#pragma clang fp contract(off)
+    if (octaves == 1) return pn_noise3(x, y, z, 1024);
+    float freq = 1.0f, amp = 1.0f, top = 0.0f, total = 0.0f;
+    for (int o = 0; o < octaves; o++) {
+        total += pn_noise3(x * freq, y * freq, z * freq, (int)(1024 * freq)) * amp;
+        top += amp;
+        freq *= 2.0f;
+        amp *= 0.5f;
+    }
+    return total / top;
+}
+// PerturbedPattern._perturb (shapes.py:1911-1922): the world point moved by three noise samples one apart in z
+template <class R> __device__ __noinline__ V3<R> perturb_point(const DScene<R>& S, int node, V3<R> pt) {
+    const R freq = S.pat_param[4 * node], scale = S.pat_param[4 * node + 1];
+    const int octaves = (int)S.pat_param[4 * node + 2];
+    const R x = pt.x / freq, y = pt.y / freq;
+    R z = pt.z / freq;
+    V3<R> out;
+    out.x = pt.x + R(pn_pnoise3((float)x, (float)y, (float)z, octaves)) * scale;
+    z += R(1);
+    out.y = pt.y + R(pn_pnoise3((float)x, (float)y, (float)z, octaves)) * scale;
+    z += R(1);
+    out.z = pt.z + R(pn_pnoise3((float)x, (float)y, (float)z, octaves)) * scale;
+    return out;
+}
+
 // material colour at a world point: plain colour, or the pattern program (postfix over a colour stack)
-template <class R> __device__ __forceinline__ V3<R> surface_color(const DScene<R>& S, int material, int leaf, V3<R> wp) {
+// EXT = the kernel variant for scenes with CSG objects or perturbed patterns (rtc_api.hip): only it carries the noise code
+template <class R, bool EXT> __device__ __forceinline__ V3<R> surface_color(const DScene<R>& S, int material, int leaf, V3<R> wp) {
     int prog = S.mat_program[material];
     const R* mc = S.mat + 10 * (size_t)material;
     if (prog < 0) return mk<R>(mc[0], mc[1], mc[2]);
     V3<R> op = xpoint(S.xform + 12 * (size_t)S.leaf_xform[leaf], wp);   // shape.world_to_object (shapes.py:1664)
     int off = S.prog_off[prog], len = S.prog_len[prog];
     V3<R> stack[RTC_PAT_STACK];
-    int sp = 0;
+    V3<R> outer0 = wp, outer1 = wp;        // the points PERTURB replaced (RTC_PERTURB_DEPTH = 2)
+    int sp = 0, moved = 0;
     for (int i = 0; i < len; i++) {
         int opc = S.instr[2 * (off + i)], node = S.instr[2 * (off + i) + 1];
+        if (EXT && opc >= RTC_OP_PERTURB) {
+            if (opc == RTC_OP_PERTURB) {
+                if (moved++ == 0) outer0 = wp; else outer1 = wp;
+                wp = perturb_point(S, node, wp);
+            } else {
+                wp = --moved == 0 ? outer0 : outer1;
+            }
+            op = xpoint(S.xform + 12 * (size_t)S.leaf_xform[leaf], wp);
+            continue;
+        }
         if (opc == RTC_OP_BLEND) {
             V3<R> q = stack[--sp], p = stack[--sp];
             stack[sp++] = (p + q) * R(0.5);
@@ -937,7 +1026,7 @@ __device__ __forceinline__ V3<R> shade_ray(const DScene<R>& S, const Ray<R>& ray
         if (S.refraction_matters && needs_containers(S.mat[10 * (size_t)c.material + 8], remaining)) container_n1n2(S, ray, c.t, c.leaf, stack, cnt, n1, n2);
         Secondary<R> sec = secondary_rays(S, c, remaining, n1, n2);
         if (!emit(sec.refl, c.over_point, c.reflectv, sec.w_refl, sec.refr, c.under_point, sec.refr_dir, sec.w_refr)) return surface;
-        V3<R> pcolor = surface_color(S, c.material, c.leaf, c.over_point);
+        V3<R> pcolor = surface_color<R, CNT::kCsg>(S, c.material, c.leaf, c.over_point);
         for (int l = 0; l < S.n_lights; l++) {
             V3<R> amb, mean;
             const bool matters = light_terms(S, c, pcolor, l, cnt, seed, pixel, path, amb, mean);

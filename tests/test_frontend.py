@@ -214,8 +214,16 @@ def test_pattern_programs():
     cs = compile_scene(World([], [s]))
     ops = cs.arrays["instr"][:cs.counts["n_instr"], 0].tolist()
     assert ops == [0, 0, 0, 2, 1]                                    # stripe, ring, gradient, BLEND, EVAL_AB(checkers)
-    s.material.pattern = S.PerturbedPattern(S.Stripe(W, B))
-    with pytest.raises(NotImplementedError):
+    # PERTURB / RESTORE bracket the wrapped pattern's program (shapes.py:1924-1925); the node carries frequency, scale, octaves
+    s.material.pattern = S.PerturbedPattern(S.BlendedPattern(S.Stripe(W, B), S.PerturbedPattern(S.Ring(W, B), 0.2, 0.1, 3)))
+    cs = compile_scene(World([], [s]))
+    ops = cs.arrays["instr"][:cs.counts["n_instr"], 0].tolist()
+    assert ops == [3, 0, 3, 0, 4, 2, 4]
+    outer, inner = cs.arrays["instr"][0, 1], cs.arrays["instr"][2, 1]
+    assert cs.arrays["pat_type"][outer] == 8 and cs.arrays["pat_param"][outer][:3].tolist() == [0.4, 0.3, 1.0]
+    assert cs.arrays["pat_param"][inner][:3].tolist() == [0.2, 0.1, 3.0]
+    s.material.pattern = S.PerturbedPattern(S.Stripe(W, B), octaves=0)          # noise.pnoise3 raises for octaves < 1
+    with pytest.raises(ValueError):
         compile_scene(World([], [s]))
 
 

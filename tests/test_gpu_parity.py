@@ -18,7 +18,8 @@ pytestmark = pytest.mark.gpu
 CASES = [("cover", None, 1), ("csg_test", (192, 192), 1), ("group", None, 1), ("checkered_sphere", (160, 160), 1),
          ("checkered_plane", (160, 160), 1), ("checkered_cylinder", (160, 160), 1), ("align_check_plane", (160, 160), 1),
          ("checkered_cube", (320, 160), 1), ("earth", (320, 160), 1), ("skybox", (320, 160), 1),
-         ("shadow_glamour_shot_nojitter", (240, 96), 1), ("teapot", None, 3), ("dragons", (480, 192), 16)]
+         ("shadow_glamour_shot_nojitter", (240, 96), 1), ("teapot", None, 3), ("dragons", (480, 192), 16),
+         ("perturbed", (320, 200), 1)]          # perturbed patterns: noise restated from the published algorithm, parity unpinned
 GOLDEN = [c[0] for c in CASES]
 
 

@@ -380,3 +380,66 @@ def test_matrix_inverse():             # matrix.py:352-376
     assert np.allclose(b.arr[2], [-0.02901235, -0.1462963, -0.10925926, 0.12962963], atol=1e-8)
     with pytest.raises(ValueError):
         inverse(matrix(-4, 2, -2, -3, 9, 6, 2, 6, 0, -5, 1, -5, 0, 0, 0, 0))
+
+
+# ---------------------------------------------------------------- PerturbedPattern / pnoise3 (parity UNPINNED)
+# The PyPI `noise` package is in neither the reference tree nor this image and no file of the reference holds an output of
+# it, so these are not known answers of the reference: they hold the C restatement (oracle/rtc_oracle.c) against a second,
+# independent transcription of the same published algorithm (oracle/_stubs/noise.py) and against the algorithm's own
+# invariants.  The reference's PerturbedPattern code around the noise IS pinned: tests/golden/perturbed.npz.
+def _stub_noise():
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_stubs", "noise.py")
+    spec = importlib.util.spec_from_file_location("_rtc_noise_stub", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_pnoise3_two_transcriptions_agree():
+    from oracle.oracle import pnoise3
+    stub = _stub_noise()
+    rng = np.random.default_rng(11)
+    for _ in range(400):
+        x, y, z = rng.uniform(-60, 60, 3)
+        octaves = int(rng.integers(1, 8))
+        assert pnoise3(x, y, z, octaves) == stub.pnoise3(x, y, z, octaves)
+
+
+def test_pnoise3_invariants():
+    from oracle.oracle import pnoise3
+    rng = np.random.default_rng(12)
+    # gradient noise vanishes on the integer lattice (every corner contributes gradient . 0)
+    for p in rng.integers(-300, 300, (50, 3)):
+        assert pnoise3(*p) == 0.0
+    # bounded, not constant, continuous, and periodic with the package's default repeat of 1024
+    pts = rng.uniform(-20, 20, (2000, 3))
+    vals = np.array([pnoise3(*p) for p in pts])
+    assert np.abs(vals).max() <= 1.0 and vals.std() > 0.1
+    step = np.array([pnoise3(*(p + 1e-3)) for p in pts[:300]])
+    assert np.abs(step - vals[:300]).max() < 0.01
+    for p in rng.uniform(0, 50, (50, 3)):
+        assert abs(pnoise3(*p) - pnoise3(p[0] + 1024, p[1], p[2] + 1024)) < 1e-3      # float32 coordinates: not bit-equal
+    # octaves: the sum of the octaves over the sum of the amplitudes
+    x, y, z = 0.37, 1.21, -2.6
+    two = (pnoise3(x, y, z) + 0.5 * pnoise3(2 * x, 2 * y, 2 * z)) / 1.5
+    assert abs(pnoise3(x, y, z, 2) - two) < 1e-6
+    assert np.isnan(pnoise3(x, y, z, 0))                                              # the package raises ValueError
+
+
+def test_perturbed_pattern_moves_the_world_point():      # shapes.py:1911-1925
+    from oracle.oracle import Oracle, pnoise3
+    inner = S.Pattern()                                  # the book's test pattern: colour = pattern-space point
+    inner.transform = translation(0.5, 1, 1.5)
+    pat = S.PerturbedPattern(inner, frequency=0.4, scale_factor=0.3, octaves=3)
+    sh = S.sphere()
+    sh.transform = scaling(2, 2, 2)
+    sh.material.pattern = pat
+    w = world_of(sh)
+    p = np.array([1.3, -0.4, 0.8])
+    got = Oracle(w).pattern_at_shape(pat, sh, point(*p))
+    q = p / 0.4
+    moved = p + 0.3 * np.array([pnoise3(q[0], q[1], q[2], 3), pnoise3(q[0], q[1], q[2] + 1.0, 3), pnoise3(q[0], q[1], q[2] + 2.0, 3)])
+    want = moved / 2 - np.array([0.5, 1, 1.5])           # world -> object (the sphere's scaling) -> pattern space
+    assert np.allclose(got, want, atol=1e-12)

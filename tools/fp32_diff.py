@@ -29,3 +29,7 @@ with _ffi.Scene(compile_scene(world)) as sc:
     for x, y in bad[:40]:
         print(x, y, "ids", ia[x, y], ib[x, y], "kind", compile_scene(world).arrays["leaf_kind"][ia[x, y]] if ia[x, y] >= 0 else -1,
               "f64", np.round(a[x, y], 4), "f32", np.round(b[x, y], 4))
+    # per primary-hit leaf: how many of its pixels are off
+    for leaf in np.unique(ia):
+        sel = ia == leaf
+        print("leaf %d: %d px, %d off" % (leaf, sel.sum(), (d.T[sel] > 1).sum()))

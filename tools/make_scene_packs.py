@@ -56,8 +56,14 @@ def pack(name, yaml_path, cwd, meta=None, edit=None):
     print("%-32s %8.1f KB" % (name, os.path.getsize(out) / 1024.0))
 
 
-def main():
+def main(which=()):
     os.makedirs(OUT, exist_ok=True)
+    # a scene of this repository's own (scenes/src/): perturbed patterns, which no scene file of the reference uses
+    if not which or "perturbed" in which:
+        pack("perturbed", os.path.join(OUT, "src", "perturbed.yml"), OUT,
+             {"source": "scenes/src/perturbed.yml (this repository)", "note": "noise = restated pnoise3, parity unpinned"})
+    if which and "reference" not in which:
+        return
     tm = os.path.join(REF, "texture_mapping")
     pack("cover", os.path.join(REF, "cover/cover.yml"), REF)
     pack("csg_test", os.path.join(REF, "csg_test.yml"), REF)
@@ -86,4 +92,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    main(sys.argv[1:])          # no argument: every pack; `perturbed`: only this repository's own scene
