@@ -31,7 +31,8 @@ typedef enum {
     RTC_ERR_NO_DEVICE = -2, /* no usable GPU, or device index out of range */
     RTC_ERR_HIP = -3,       /* a HIP runtime call failed (message has the HIP error string) */
     RTC_ERR_LIMIT = -4,     /* scene exceeds a compiled-in limit (CSG hits, pattern stack, BVH depth) */
-    RTC_ERR_UNSUPPORTED = -5
+    RTC_ERR_UNSUPPORTED = -5,
+    RTC_ERR_NOMEM = -6      /* host memory exhausted while building the scene (no C++ exception crosses this ABI) */
 } rtc_status;
 
 /* primitive kinds (shapes.py class -> code) */

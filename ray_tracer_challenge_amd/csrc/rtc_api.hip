@@ -8,6 +8,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <new>
+#include <stdexcept>
 #include <string>
 #include <type_traits>
 #include <vector>
@@ -949,11 +951,19 @@ int rtc_scene_create(const rtc_scene_desc* desc, int device, rtc_scene** out) {
     if (n <= 0) return fail(RTC_ERR_NO_DEVICE, "no GPU visible to HIP");
     if (device < 0 || device >= n) return fail(RTC_ERR_NO_DEVICE, "device %d out of range (%d visible)", device, n);
     HIP_TRY(hipSetDevice(device));
-    rtc_scene* sc = new rtc_scene();
-    sc->device = device;
-    sc->n_leaves = desc->n_leaves;
-    int rc = create_impl(*desc, sc);
-    if (rc) { rtc_scene_destroy(sc); return rc; }
+    rtc_scene* sc = nullptr;
+    int rc = 0;
+    try {                                           // the BVH build and the staging copies allocate host memory
+        sc = new rtc_scene();
+        sc->device = device;
+        sc->n_leaves = desc->n_leaves;
+        rc = create_impl(*desc, sc);
+    } catch (const std::bad_alloc&) {
+        rc = fail(RTC_ERR_NOMEM, "out of host memory while building the scene");
+    } catch (const std::exception& e) {
+        rc = fail(RTC_ERR_INVALID, "scene build failed: %s", e.what());
+    }
+    if (rc) { if (sc) rtc_scene_destroy(sc); return rc; }
     *out = sc;
     return 0;
 }
@@ -1010,6 +1020,7 @@ int update_triangles_impl(rtc_scene* scene, int64_t n_tris, const double* tri_ge
     std::lock_guard<std::mutex> lock(scene->ws_mutex);
     HIP_TRY(hipDeviceSynchronize());
     const size_t n = 12 * (size_t)n_tris;
+    try {
     if (on_device) {
         hipLaunchKernelGGL(rtc::tri_rows_from_device_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, (long long)n, tri_geom, tri_norm,
                            const_cast<double*>(scene->d64.tri_geom), const_cast<double*>(scene->d64.tri_norm),
@@ -1023,6 +1034,9 @@ int update_triangles_impl(rtc_scene* scene, int64_t n_tris, const double* tri_ge
     HIP_TRY(hipMemcpy(const_cast<float*>(scene->d32.tri_geom), g32.data(), n * sizeof(float), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(const_cast<float*>(scene->d32.tri_norm), n32.data(), n * sizeof(float), hipMemcpyHostToDevice));
     return refit ? refit_triangle_bvh_device(scene) : rebuild_triangle_bvh_device(scene);
+    } catch (const std::bad_alloc&) {
+        return fail(RTC_ERR_NOMEM, "out of host memory while staging the triangle rows");
+    }
 }
 }  // namespace
 
