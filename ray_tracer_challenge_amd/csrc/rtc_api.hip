@@ -550,13 +550,15 @@ int create_impl(const rtc_scene_desc& d, rtc_scene* sc) {
     S.n_tnodes = tbvh.n_nodes();
     S.n_unbounded = d.n_unbounded;
     S.n_lights = d.n_lights;
+    S.n_flat_prims = (oprim.size() >= 2 && oprim.size() <= 4 && obj_leaf >= 4 && bvh.n_nodes() == 1) ? (int32_t)oprim.size() : 0;
+    if (getenv("RTC_NO_FLAT")) S.n_flat_prims = 0;          // development: force the BVH walk
     S.refraction_matters = 0;
     for (int i = 0; i < d.n_materials; i++) if (d.mat[10 * (size_t)i + 9] != 1.0) S.refraction_matters = 1;
 
     rtc::DScene<float>& F = sc->d32;
 #define CP(field) F.field = S.field
     CP(n_leaves); CP(leaf_kind); CP(leaf_xform); CP(leaf_material); CP(leaf_tri); CP(leaf_closed); CP(tri_leaf);
-    CP(n_bvh_nodes); CP(bvh_prims); CP(n_tnodes); CP(tb_leaf); CP(n_unbounded); CP(unbounded_prims); CP(csg_root); CP(csg_node);
+    CP(n_bvh_nodes); CP(bvh_prims); CP(n_flat_prims); CP(n_tnodes); CP(tb_leaf); CP(n_unbounded); CP(unbounded_prims); CP(csg_root); CP(csg_node);
     CP(mat_shadow); CP(mat_program); CP(pat_type); CP(pat_child); CP(pat_tex); CP(prog_off); CP(prog_len); CP(instr);
     CP(tex_off); CP(tex_w); CP(tex_h); CP(tex_data); CP(n_lights); CP(refraction_matters); CP(light_type); CP(light_steps);
 #undef CP
