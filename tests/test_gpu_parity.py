@@ -503,3 +503,32 @@ def test_refit_follows_a_deforming_mesh():
         sc.update_triangles_device(tg.data_ptr(), tn.data_ptr(), len(g2), refit=False)
         h, ih = sc.render(cam, precision="fp64", want_ids=True)
         _same_image(want2, h, ids2, ih)
+
+
+def test_result_arrays_come_from_the_pinned_pool(scenes):
+    """_ffi draws result arrays from page-locked blocks (rtc_host_alloc): two results never share memory while both are
+    alive, a released block is handed out again, and views keep their block alive."""
+    import gc
+    cam, world, sc = scenes("cover")
+    cam = cam.resized(256, 128)                       # 786 KB frame: above the pool's small-array cut-off
+    a, _ = sc.render(cam, precision="fp64")
+    keep = a.copy()
+    b, _ = sc.render(cam, precision="fp32")
+    assert a.ctypes.data != b.ctypes.data
+    np.testing.assert_array_equal(a, keep)            # the second render did not write into the first result
+    view = a[10:20]
+    addr = a.ctypes.data
+    del a
+    gc.collect()
+    c, _ = sc.render(cam, precision="fp64")
+    assert c.ctypes.data != addr                      # `view` still holds the block
+    np.testing.assert_array_equal(view, keep[10:20])
+    del view
+    gc.collect()
+    d, _ = sc.render(cam, precision="fp64")
+    assert d.ctypes.data == addr                      # released block reused
+    np.testing.assert_array_equal(d, keep)
+    # the C entry points themselves
+    p = C.c_void_p()
+    assert _ffi.lib().rtc_host_alloc(1 << 20, C.byref(p)) == 0 and p.value
+    _ffi.lib().rtc_host_free(p)
