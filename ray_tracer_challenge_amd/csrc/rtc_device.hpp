@@ -570,10 +570,15 @@ template <class R, class CNT> struct ContainerVisitor {
     __device__ __forceinline__ bool done() const { return false; }
     __device__ __forceinline__ bool tri(int pos) {
         R t, tu, tv;
+        const int leaf = S.tb_leaf[pos] & 0x7FFFFFFF;
+        if (leaf == x_leaf) return false;        // the hit triangle's one intersection is the hit itself: nothing precedes it
         cnt.work(W_TRI);
-        if (tri_hit(S.tb_geom + 12 * (size_t)pos, ray, t, tu, tv) && t < t_hit) account(S.tb_leaf[pos] & 0x7FFFFFFF, 1, t);
+        if (tri_hit(S.tb_geom + 12 * (size_t)pos, ray, t, tu, tv) && t < t_hit) account(leaf, 1, t);
         return false;
     }
+    // Which intersections of the hit leaf X precede the hit must not hang on this pass recomputing the hit's t to the
+    // last bit (one ulp below t_hit would count the hit as its own predecessor and turn an entry into an exit): the hit
+    // is X's intersection nearest t_hit, and what precedes it is what is smaller than THAT value.
     __device__ __forceinline__ void account(int leaf, int count, R last) {
         if (!(count & 1)) return;
         if (leaf == x_leaf) { x_odd = true; x_last = last; }
@@ -585,14 +590,19 @@ template <class R, class CNT> struct ContainerVisitor {
             CsgHits<R> H;
             cnt.work(W_CSG);
             csg_hits(S, p.idx, ray, H);
-            for (int i = 0; i < H.n; i++) {
-                if (!(H.t[i] < t_hit)) break;
+            // the sorted list is cut at the hit: at X's entry nearest t_hit if X belongs to this root, else by value
+            int cut = -1;
+            R nearest = inf_<R>();
+            for (int i = 0; i < H.n; i++)
+                if (H.leaf[i] == x_leaf && abs_(H.t[i] - t_hit) < nearest) { nearest = abs_(H.t[i] - t_hit); cut = i; }
+            if (cut < 0) { cut = 0; while (cut < H.n && H.t[cut] < t_hit) cut++; }
+            for (int i = 0; i < cut; i++) {
                 int leaf = H.leaf[i];
                 bool seen = false;
                 for (int j = 0; j < i; j++) seen = seen || H.leaf[j] == leaf;
                 if (seen) continue;
                 int cnt = 0; R last = -inf_<R>();
-                for (int j = i; j < H.n && H.t[j] < t_hit; j++) if (H.leaf[j] == leaf) { cnt++; last = H.t[j]; }
+                for (int j = i; j < cut; j++) if (H.leaf[j] == leaf) { cnt++; last = H.t[j]; }
                 account(leaf, cnt, last);
             }
             return false;
@@ -600,8 +610,13 @@ template <class R, class CNT> struct ContainerVisitor {
         R t[4], tu, tv;
         cnt.work(W_LEAF);
         int leaf = p.idx, n = leaf_hits(S, leaf, ray, t, tu, tv);
+        R bound = t_hit;
+        if (leaf == x_leaf) {
+            R nearest = inf_<R>();
+            for (int k = 0; k < n; k++) if (abs_(t[k] - t_hit) < nearest) { nearest = abs_(t[k] - t_hit); bound = t[k]; }
+        }
         int cnt = 0; R last = -inf_<R>();
-        for (int k = 0; k < n; k++) if (t[k] < t_hit) { cnt++; last = max_(last, t[k]); }
+        for (int k = 0; k < n; k++) if (t[k] < bound) { cnt++; last = max_(last, t[k]); }
         account(leaf, cnt, last);
         return false;
     }
@@ -634,8 +649,11 @@ template <class R> __device__ __forceinline__ V3<R> normal_at(const DScene<R>& S
     default: {   // cylinder / cone: caps by `dist < 1` in both (shapes.py:676-687, 767-774)
         R dist = p.x * p.x + p.z * p.z;
         R minimum = S.leaf_minmax[2 * leaf], maximum = S.leaf_minmax[2 * leaf + 1];
-        if (dist < R(1) && (maximum - RTC_EPS) < p.y) n = mk<R>(0, 1, 0);
-        else if (dist < R(1) && (minimum + RTC_EPS) > p.y) n = mk<R>(0, -1, 0);
+        // fp32 only: a hit point brought back to object space is off by ~1e-6 x its world coordinates, which is the
+        // reference's whole EPSILON -- a point on a cap would pass for a wall point and get the wall's normal
+        const R cap_eps = sizeof(R) == 4 ? R(1e-4) : RTC_EPS;
+        if (dist < R(1) && (maximum - cap_eps) < p.y) n = mk<R>(0, 1, 0);
+        else if (dist < R(1) && (minimum + cap_eps) > p.y) n = mk<R>(0, -1, 0);
         else if (kind == RTC_CYLINDER) n = mk<R>(p.x, 0, p.z);
         else { R y = sqrt_(dist); if (p.y > R(0)) y = -y; n = mk<R>(p.x, y, p.z); }
         break;
