@@ -246,3 +246,62 @@ def test_random_mesh_world(seed, oracle_cls):
         sc.update_triangles(cs.arrays["tri_geom"], cs.arrays["tri_norm"], refit=True)      # same rows: same boxes, same frame
         r, ri = sc.render(cam, precision="fp64", want_ids=True)
         np.testing.assert_array_equal(r, g)
+
+
+def _csg_tree(rng, depth, anchor):
+    """Nested CSG: operands are primitives, groups of primitives or further CSG nodes, all overlapping around `anchor`."""
+    def operand(d):
+        r = rng.random()
+        if d > 0 and r < 0.35:
+            return _csg_tree(rng, d - 1, anchor)
+        if r < 0.5:
+            g = S.Group(_material(rng), anchor * _small_transform(rng), [])
+            for _ in range(2):
+                c = _primitive(rng, False)
+                c.transform = translation(*rng.uniform(-0.4, 0.4, 3)) * scaling(*rng.uniform(0.5, 1.1, 3))
+                g.add_child(c)
+            return g
+        p = _primitive(rng, False)
+        p.transform = anchor * translation(*rng.uniform(-0.5, 0.5, 3)) * rotation_y(rng.uniform(0, 6.28)) * scaling(*rng.uniform(0.6, 1.3, 3))
+        return p
+    op = [S.CSGUnion, S.CSGIntersect, S.CSGDifference][rng.integers(3)]
+    return S.CSG(_material(rng), None, op, operand(depth), operand(depth))
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("RTC_FUZZ_SEEDS", "16"))))
+def test_random_csg_world(seed, oracle_cls):
+    """CSG route: one to three nested CSG trees (operands: primitives, groups, CSG), transparent and reflective parts,
+    a floor and sometimes an extra primitive, so that both CSG-only (single item) and mixed scenes occur."""
+    rng = np.random.default_rng(5000 + seed)
+    _SPREAD[0] = 1.0
+    objs = []
+    for k in range(int(rng.integers(1, 4))):
+        anchor = translation(*rng.uniform(-1.6, 1.6, 3)) * rotation_x(rng.uniform(0, 6.28)) * rotation_z(rng.uniform(0, 6.28))
+        try:
+            tree = _csg_tree(rng, 2, anchor)
+            compile_scene(World([], [tree]))                               # the 32-hits-per-ray limit
+        except NotImplementedError:
+            continue
+        objs.append(tree)
+    if not objs or rng.random() < 0.4:
+        objs.append(_primitive(rng))
+    if rng.random() < 0.7:
+        floor = S.Plane(_material(rng), translation(0, -2.8, 0))
+        floor.material.transparency = np.float64(0.0)
+        objs.append(floor)
+    lights = [point_light(point(*(rng.uniform(-5, 5, 3) + np.array([0, 7, -5]))), _rgb(rng, 0.5, 1.0))]
+    cam = Camera(HSIZE, VSIZE, 0.9, view_transform(point(0.3, 2.5, -6.5), point(0, -0.2, 0), vector(0, 1, 0)))
+    world = World(lights, objs)
+    xs, ys = np.meshgrid(np.arange(HSIZE), np.arange(VSIZE), indexing="ij")
+    want, leaf, t_hit, rays = oracle_cls(world).render_pixels(cam, xs.ravel(), ys.ravel())
+    want, leaf = want.reshape(HSIZE, VSIZE, 3), leaf.reshape(HSIZE, VSIZE)
+    near = (~(np.isfinite(t_hit) & (t_hit > 60.0))).reshape(HSIZE, VSIZE)
+    with _ffi.Scene(compile_scene(world), device=0) as sc:
+        rgb, ids = sc.render(cam, precision="fp64", want_ids=True)
+        lv, _ = sc.render(cam, precision="fp64", wavefront=True)
+        f32, _ = sc.render(cam, precision="fp32")
+    off = np.abs(rgb - want).max(axis=2) > 1e-9
+    print("csg seed %d: fp64 off %d, ids %d, fp32 off>1 %.4f" % (seed, off.sum(), (ids != leaf).sum(), frac_off_by_more_than_one(f32[near], want[near])))
+    assert off.mean() <= 0.004 and (ids != leaf).mean() <= 0.004
+    assert (np.abs(lv - rgb).max(axis=2) > 1e-9).mean() <= 0.002
+    assert frac_off_by_more_than_one(f32[near], want[near]) <= 0.02
