@@ -162,6 +162,10 @@ def main():
     work = [int(v) for v in rays_dev[4:12].tolist()]
     dt32, rays32 = timed("fp32", args.steps, args.warmup)
     kms32 = kernel_only("fp32", max(3, min(args.steps, 10)))
+    rays_dev.zero_()
+    step("fp32", count_work=True)
+    sync()
+    work32 = [int(v) for v in rays_dev[4:12].tolist()]
     # for the record: the same frames launched in plain tile order (no cost feedback from the previous frame)
     plain = None
     if world == 1:
@@ -193,7 +197,10 @@ def main():
             "launch_order": {"policy": "dearest 8x8 blocks first, from the wave costs the first two frames of a view record",
                              "ms_per_frame_plain_tile_order": None if plain is None else round(plain, 4)},
             "fp32": {"value": round(sum(rays32[:4]) / dt32 / 1e6, 3), "unit": "Mrays/s", "ms_per_frame": round(dt32 / args.steps * 1e3, 4),
-                     "kernel_ms": round(kms32, 4)},
+                     "kernel_ms": round(kms32, 4),
+                     "roofline": {"bound": "valu", "achieved": round(algorithmic_flops(work32) / (kms32 * 1e-3) / 1e12, 4),
+                                  "peak": PEAK_TFLOPS["fp32"], "unit": "TFLOP/s",
+                                  "frac": round(algorithmic_flops(work32) / (kms32 * 1e-3) / 1e12 / PEAK_TFLOPS["fp32"], 5)}},
             "roofline": {"bound": "valu", "achieved": round(achieved, 4), "peak": PEAK_TFLOPS["fp64"], "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_TFLOPS["fp64"], 5), "traffic": traffic,
                          "kernel": "trace_kernel<double, false, %s>" % ("true" if cs.counts.get("n_csg_roots") else "false"), "kernel_ms": round(kms64, 4),
