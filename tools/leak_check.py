@@ -1,0 +1,33 @@
+"""Device and pinned-host memory must not grow over many calls of every entry point.  Usage: leak_check.py [iterations]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from ray_tracer_challenge_amd import _ffi
+from ray_tracer_challenge_amd.compile import compile_scene
+from ray_tracer_challenge_amd.scene_io import load_world
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+cam, world, _ = load_world(os.path.join(ROOT, "scenes", "teapot.npz"))
+cam = cam.resized(640, 360)
+cs = compile_scene(world)
+free = lambda: torch.cuda.mem_get_info(0)[0]
+torch.zeros(1, device="cuda:0")
+marks = []
+for it in range(n):
+    with _ffi.Scene(cs) as sc:
+        sc.render(cam, precision="fp64", want_ids=True)
+        sc.render(cam, precision="fp32", wavefront=True)
+        sc.render_ppm(cam)
+        sc.render_tiles(cam, np.arange(0, 40, 3, dtype=np.int32), want_ids=True)
+        sc.update_triangles(cs.arrays["tri_geom"], cs.arrays["tri_norm"], refit=True)
+        sc.build_bvh_on_device()
+        sc.update_triangles(cs.arrays["tri_geom"], cs.arrays["tri_norm"])
+        sc.render(cam, precision="fp64")
+    if it % (n // 4) == 0 or it == n - 1:
+        torch.cuda.synchronize()
+        marks.append((it, free() / 2**20, _ffi._pinned.total / 2**20))
+        print("iteration %d: device free %.1f MiB, pinned pool %.1f MiB" % marks[-1], flush=True)
+assert abs(marks[-1][1] - marks[1][1]) < 64, "device memory drifted"
+assert marks[-1][2] <= 1024
+print("no growth")
