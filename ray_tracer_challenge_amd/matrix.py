@@ -44,8 +44,13 @@ def matrix(*args):
     return Matrix(np.array(args, dtype=np.float64).reshape(n, n))
 
 
+_EYE4 = np.eye(4)
+
+
 def matrix4x4identity():
-    return Matrix(np.eye(4))
+    m = Matrix.__new__(Matrix)          # every shape gets its own (an OBJ mesh: one per triangle), so skip the conversions
+    m.arr = _EYE4.copy()
+    return m
 
 
 def matrix_multiply(a, b):
