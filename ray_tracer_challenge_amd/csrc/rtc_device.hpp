@@ -296,8 +296,14 @@ template <class R> __device__ __forceinline__ int leaf_hits(const DScene<R>& S, 
         return tri_hit(S.tri_geom + 12 * (size_t)S.leaf_tri[leaf], ray, t[0], u, v) ? 1 : 0;
     }
     const R* m = S.xform + 12 * (size_t)S.leaf_xform[leaf];
+    if (kind == RTC_PLANE) {
+        // the plane test reads only the y row of the object-space ray (shapes.py:546-552): the same two expressions
+        // xpoint / xvector evaluate for it, without the other four
+        Ray<R> ry = {mk<R>(R(0), m[4] * ray.o.x + m[5] * ray.o.y + m[6] * ray.o.z + m[7], R(0)),
+                     mk<R>(R(0), m[4] * ray.d.x + m[5] * ray.d.y + m[6] * ray.d.z, R(0))};
+        return plane_hits(ry, t);
+    }
     Ray<R> r = {xpoint(m, ray.o), xvector(m, ray.d)};   // shapes.py:271-273, 1447-1448
-    if (kind == RTC_PLANE) return plane_hits(r, t);
     if (kind == RTC_CUBE) return cube_hits(r, t);
     // fp32 only: solve the quadratic from the point of the ray nearest the object's origin and add
     // the shift back.  Same roots; it keeps b^2 - 4ac from cancelling when the eye is far from a
@@ -961,6 +967,10 @@ __device__ __forceinline__ bool light_terms(const DScene<R>& S, const HitCtx<R>&
     amb = effective * ambient;
     LightShape ls = light_shape(S, l);
     V3<R> acc = mk<R>(0, 0, 0);
+    // a coefficient of exactly 0 makes its term +0 whatever the geometry (renderer.py:1083-1090): the specular pow() --
+    // the dearest thing in this loop -- is skipped for matte materials, the whole loop for materials that are neither
+    const bool has_specular = specular != R(0);
+    if (diffuse == R(0) && !has_specular) { mean = acc; return false; }
     for (int v = 0; v < ls.vsteps; v++)
         for (int u = 0; u < ls.usteps; u++) {
             V3<R> pos = light_sample<R>(S, l, ls, u, v, seed, pixel, path, 2);
@@ -969,9 +979,11 @@ __device__ __forceinline__ bool light_terms(const DScene<R>& S, const HitCtx<R>&
             R ldn = dot(lightv, c.normalv);
             if (ldn >= R(0)) {
                 acc = acc + effective * diffuse * ldn;
-                V3<R> reflectv = reflect(neg(lightv), c.normalv);
-                R rde = dot(reflectv, c.eyev);
-                if (rde > R(0)) acc = acc + lint * specular * pow_(rde, shininess);
+                if (has_specular) {
+                    V3<R> reflectv = reflect(neg(lightv), c.normalv);
+                    R rde = dot(reflectv, c.eyev);
+                    if (rde > R(0)) acc = acc + lint * specular * pow_(rde, shininess);
+                }
             }
         }
     mean = mk<R>(acc.x / R(ls.samples), acc.y / R(ls.samples), acc.z / R(ls.samples));
