@@ -162,7 +162,7 @@ class _Compiler(object):
             if kind in (K_CYLINDER, K_CONE):
                 minmax = (float(obj.minimum), float(obj.maximum))
                 closed = 1 if obj.closed else 0
-            lo, hi = self._analytic_bounds(kind, minmax, m)
+            lo, hi = self._analytic_bounds(kind, minmax, m, closed)
         self.leaf_minmax.append(minmax)
         self.leaf_closed.append(closed)
         self.leaf_lo.append(lo)
@@ -171,8 +171,11 @@ class _Compiler(object):
             (self.items if (kind == K_TRIANGLE or lo is not None) else self.unbounded).append((kind, leaf))
 
     @staticmethod
-    def _analytic_bounds(kind, minmax, m):
-        """World AABB of the leaf's local bounds (shapes.py:298-300, 561-562, 708-713, 795-796)."""
+    def _analytic_bounds(kind, minmax, m, closed=0):
+        """World AABB of what the leaf's local_intersect can report (shapes.py:298-300, 561-562, 708-713, 795-796).
+        For a closed cone that is MORE than the reference's own bounds(): its cap test accepts x^2 + z^2 <= |y|
+        (shapes.py:689-693: |y|, not y^2), a disc of radius sqrt|y| -- a brim around the cone wherever |y| < 1 -- and
+        the reference, which never culls, renders it; a box without the brim would cull those hits away."""
         if kind == K_PLANE:
             return None, None
         if kind in (K_SPHERE, K_CUBE):
@@ -181,6 +184,8 @@ class _Compiler(object):
             if not (np.isfinite(minmax[0]) and np.isfinite(minmax[1])):
                 return None, None
             r = 1.0 if kind == K_CYLINDER else max(abs(minmax[0]), abs(minmax[1]))
+            if kind == K_CONE and closed:
+                r = max(r, np.sqrt(r))
             l, h = np.array([-r, minmax[0], -r]), np.array([r, minmax[1], r])
         a = np.linalg.inv(m)
         corners = np.array([[x, y, z, 1.0] for x in (l[0], h[0]) for y in (l[1], h[1]) for z in (l[2], h[2])])
