@@ -144,7 +144,12 @@ def random_world(seed):
     return cam, World(lights, objs)
 
 
-@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("RTC_FUZZ_SEEDS", "48"))))
+# the worlds that exposed the defects named above stay in the default run: 110 / 215 (container pass, fp32 glass), 129 (fp32 cap
+# normals), 2004 / 1595 / 2267 / 2393 (the cone's cap brim outside the reference's own bounds)
+REGRESSIONS = [110, 129, 215, 1595, 2004, 2267, 2393]
+
+
+@pytest.mark.parametrize("seed", sorted(set(range(int(__import__("os").environ.get("RTC_FUZZ_SEEDS", "48")))) | set(REGRESSIONS)))
 def test_random_world_matches_oracle(seed, oracle_cls):
     cam, world = random_world(seed)
     xs, ys = np.meshgrid(np.arange(HSIZE), np.arange(VSIZE), indexing="ij")
