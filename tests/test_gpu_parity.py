@@ -532,3 +532,24 @@ def test_result_arrays_come_from_the_pinned_pool(scenes):
     p = C.c_void_p()
     assert _ffi.lib().rtc_host_alloc(1 << 20, C.byref(p)) == 0 and p.value
     _ffi.lib().rtc_host_free(p)
+
+
+@pytest.mark.parametrize("tile", [8, 16, 64, 128])
+def test_other_tile_sizes_render_the_same_frame(tile, scenes):
+    """rtc_render_tiles with tile sizes other than the default 32 (any multiple of 8): every tile, then a strided subset,
+    scattered into a canvas, equal the plain frame pixel for pixel -- in both launch orders (the second call of a view
+    runs dearest-block-first)."""
+    cam, world, sc = scenes("cover")
+    cam = cam.resized(150, 90)                                           # not a multiple of any of the tile sizes
+    want, want_ids = sc.render(cam, precision="fp64", want_ids=True)
+    tx, ty = _ffi.tiles_for(cam.hsize, cam.vsize, tile)
+    for subset in (np.arange(tx * ty, dtype=np.int32), np.arange(tx * ty, dtype=np.int32)[::3]):
+        for _ in range(3):                                               # plain order, recorded order, steady state
+            part, part_ids = sc.render_tiles(cam, subset, precision="fp64", tile_size=tile, want_ids=True)
+            rgb, ids = np.full((cam.hsize, cam.vsize, 3), -5.0), np.full((cam.hsize, cam.vsize), -5, np.int32)
+            _ffi.scatter_tiles(rgb, ids, subset, part, part_ids, tile)
+            covered = ids != -5
+            np.testing.assert_array_equal(rgb[covered], want[covered])
+            np.testing.assert_array_equal(ids[covered], want_ids[covered])
+            if len(subset) == tx * ty:
+                assert covered.all()
