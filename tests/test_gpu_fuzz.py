@@ -310,3 +310,25 @@ def test_random_csg_world(seed, oracle_cls):
     assert off.mean() <= 0.004 and (ids != leaf).mean() <= 0.004
     assert (np.abs(lv - rgb).max(axis=2) > 1e-9).mean() <= 0.002
     assert frac_off_by_more_than_one(f32[near], want[near]) <= 0.02
+
+
+@pytest.mark.parametrize("seed", [4, 8, 11, 18, 20, 22])          # worlds with many reflection / refraction rays
+def test_random_world_at_other_depths(seed, oracle_cls):
+    """`remaining` other than the reference's default 5 (renderer.py:562): 0 (no secondary rays), 1, 3 and the library's
+    maximum 6, single kernel and level pipeline, against the oracle run with the same `remaining`."""
+    cam, world = random_world(seed)
+    xs, ys = np.meshgrid(np.arange(HSIZE), np.arange(VSIZE), indexing="ij")
+    orc = oracle_cls(world)
+    with _ffi.Scene(compile_scene(world), device=0) as sc:
+        for depth in (0, 1, 3, 6):
+            want, leaf, _, rays = orc.render_pixels(cam, xs.ravel(), ys.ravel(), remaining=depth)
+            want = want.reshape(HSIZE, VSIZE, 3)
+            st = {}
+            rgb, _ = sc.render(cam, precision="fp64", max_depth=depth, stats=st)
+            lv, _ = sc.render(cam, precision="fp64", max_depth=depth, wavefront=True)
+            assert (np.abs(rgb - want).max(axis=2) > 1e-9).mean() <= 0.003, depth
+            assert (np.abs(lv - rgb).max(axis=2) > 1e-9).mean() <= 0.002, depth
+            if depth == 0:
+                assert st["rays"][2] == 0 and st["rays"][3] == 0
+        with pytest.raises(_ffi.RtcError, match="max_depth"):
+            sc.render(cam, precision="fp64", max_depth=7)
