@@ -50,8 +50,13 @@ def _simple_pattern(rng):
     return cls(_rgb(rng), _rgb(rng), _small_transform(rng))
 
 
-def _uv_pattern(rng):
-    if rng.random() < 0.5:
+def _uv_pattern(rng, images=False):
+    r = rng.random()
+    if images and r < 0.5:                               # an image texture (earth, skybox): random texels, odd sizes
+        from ray_tracer_challenge_amd.canvas import TextureCanvas
+        h, w = int(rng.integers(3, 40)), int(rng.integers(3, 40))
+        return S.UVTexturePattern(TextureCanvas(pixels=rng.integers(0, 256, (h, w, 3)).astype(np.uint8)))
+    if r < 0.5:
         return S.UVChecker(_rgb(rng), _rgb(rng), int(rng.integers(2, 9)), int(rng.integers(2, 9)))
     return S.UVAlignCheck(_rgb(rng), _rgb(rng), _rgb(rng), _rgb(rng), _rgb(rng))
 
@@ -332,3 +337,45 @@ def test_random_world_at_other_depths(seed, oracle_cls):
                 assert st["rays"][2] == 0 and st["rays"][3] == 0
         with pytest.raises(_ffi.RtcError, match="max_depth"):
             sc.render(cam, precision="fp64", max_depth=7)
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("RTC_FUZZ_SEEDS", "12"))))
+def test_random_image_textures(seed, oracle_cls):
+    """Image textures (earth, skybox) with random texels and sizes under the planar, spherical, cylindrical and cube maps,
+    on the primitive each map is meant for and on others, rotated and scaled: texel lookup (np.round half-to-even, the
+    image maximum as the scale) against the oracle."""
+    rng = np.random.default_rng(9000 + seed)
+    _SPREAD[0] = 1.4
+    objs = []
+    for k in range(int(rng.integers(2, 6))):
+        o = _primitive(rng)
+        r = rng.random()
+        if r < 0.3:
+            pat = S.TextureMapPattern(_uv_pattern(rng, True), [S.PlaneUVMap, S.SphereUVMap][rng.integers(2)], _small_transform(rng))
+        elif r < 0.6:
+            pat = S.CylinderMapPattern(_uv_pattern(rng, True), _uv_pattern(rng, True), transform=_small_transform(rng))
+        else:
+            pat = S.CubeMapPattern(*[_uv_pattern(rng, True) for _ in range(6)], transform=_small_transform(rng))
+        o.material.pattern = pat
+        o.material.transparency = np.float64(0.0)
+        objs.append(o)
+    floor = S.Plane(_material(rng), translation(0, -2.4, 0))
+    floor.material.pattern = S.TextureMapPattern(_uv_pattern(rng, True), S.PlaneUVMap, scaling(*rng.uniform(0.5, 3, 3)))
+    floor.material.transparency = np.float64(0.0)
+    objs.append(floor)
+    lights = [point_light(point(*(rng.uniform(-5, 5, 3) + np.array([0, 7, -5]))), _rgb(rng, 0.6, 1.0))]
+    cam = Camera(HSIZE, VSIZE, 0.9, view_transform(point(0.4, 3.0, -6.0), point(0, -0.4, 0), vector(0, 1, 0)))
+    world = World(lights, objs)
+    xs, ys = np.meshgrid(np.arange(HSIZE), np.arange(VSIZE), indexing="ij")
+    want, leaf, t_hit, _ = oracle_cls(world).render_pixels(cam, xs.ravel(), ys.ravel())
+    want, leaf = want.reshape(HSIZE, VSIZE, 3), leaf.reshape(HSIZE, VSIZE)
+    near = (~(np.isfinite(t_hit) & (t_hit > 60.0))).reshape(HSIZE, VSIZE)
+    with _ffi.Scene(compile_scene(world), device=0) as sc:
+        rgb, ids = sc.render(cam, precision="fp64", want_ids=True)
+        f32, _ = sc.render(cam, precision="fp32")
+    ok = np.isfinite(want).all(axis=2)                                    # the reference raises IndexError outside an image; the oracle says NaN
+    off = (np.abs(rgb - want).max(axis=2) > 1e-9) & ok
+    print("tex seed %d: fp64 off %d, ids %d, nan px %d, fp32 off>1 %.4f" % (seed, off.sum(), (ids != leaf).sum(), (~ok).sum(),
+          frac_off_by_more_than_one(f32[near & ok], want[near & ok])))
+    assert off.mean() <= 0.004 and (ids != leaf).mean() <= 0.004
+    assert frac_off_by_more_than_one(f32[near & ok], want[near & ok]) <= 0.03      # texel boundaries are everywhere at 64 x 48
