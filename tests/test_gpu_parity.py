@@ -553,3 +553,30 @@ def test_other_tile_sizes_render_the_same_frame(tile, scenes):
             np.testing.assert_array_equal(ids[covered], want_ids[covered])
             if len(subset) == tx * ty:
                 assert covered.all()
+
+
+def test_ppm_quantisation_on_synthetic_frames():
+    """rtc_quantize_device / rtc_frame_max_device against canvas.quantize (reference canvas.py:133-156) on frames made of
+    the values where the rule could go wrong: negatives, zeros, values above the maximum, exact k/255 and (k + 0.5)/255
+    steps and their neighbours one ulp away -- clamped and scaled by the frame maximum, odd sizes."""
+    import torch
+    rng = np.random.default_rng(3)
+    for w, h in ((1, 1), (7, 5), (33, 64), (130, 3)):
+        steps = rng.integers(0, 256, (w, h, 3)) / 255.0
+        halves = (rng.integers(0, 255, (w, h, 3)) + 0.5) / 255.0
+        pick = rng.integers(0, 6, (w, h, 3))
+        frame = np.where(pick == 0, steps, np.where(pick == 1, halves, np.where(pick == 2, np.nextafter(halves, 0.0),
+                 np.where(pick == 3, np.nextafter(halves, 2.0), np.where(pick == 4, rng.uniform(-0.5, 0.0, (w, h, 3)), rng.uniform(0.0, 1.7, (w, h, 3)))))))
+        frame = np.ascontiguousarray(frame, np.float64)
+        dev = torch.from_numpy(frame).to("cuda:0")
+        stream = torch.cuda.current_stream().cuda_stream
+        top = torch.zeros(1, dtype=torch.float64, device="cuda:0")
+        assert _ffi.lib().rtc_frame_max_device(C.c_void_p(dev.data_ptr()), frame.size, C.c_void_p(top.data_ptr()), C.c_void_p(stream)) == 0
+        torch.cuda.synchronize()
+        assert float(top[0]) == frame.max()
+        for clamp in (True, False):
+            out = torch.zeros((h, w, 3), dtype=torch.uint8, device="cuda:0")
+            maxc = 1.0 if clamp else float(frame.max())
+            assert _ffi.lib().rtc_quantize_device(C.c_void_p(dev.data_ptr()), w, h, maxc, C.c_void_p(out.data_ptr()), C.c_void_p(stream)) == 0
+            torch.cuda.synchronize()
+            np.testing.assert_array_equal(out.cpu().numpy(), quantize(frame, clamp))
