@@ -17,7 +17,7 @@ def describe(p, d=0):
     return n + extra + ("(" + ", ".join(describe(q, d + 1) for q in subs) + ")" if subs else "")
 
 for seed in [int(a) for a in sys.argv[1:]]:
-    cam, world = F.random_world(seed)
+    cam, world = (F.random_texture_world(seed - 100000) if seed >= 100000 else F.random_world(seed))
     cs = compile_scene(world)
     with _ffi.Scene(cs) as sc:
         a, ia = sc.render(cam, precision="fp64", want_ids=True)
