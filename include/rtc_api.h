@@ -143,13 +143,6 @@ typedef struct {
 /* Run the instrumented kernel variant that also counts work items (slower; for roofline
  * accounting, never for timing). */
 #define RTC_FLAG_COUNT_WORK 1
-/* Use the level pipeline instead of the default single kernel: one kernel per bounce level over
- * a pool of rays in HBM (each secondary ray is its own work item, children appended with one
- * atomic per wave), then a depth-first gather that adds every pixel's subtree in a fixed order.
- * Same rays and per-ray arithmetic; a pixel's contributions are added in tree order instead of
- * as a running sum (an ulp or two).  Slower than the single kernel on every scene measured (each
- * level pays the full latency of one ray's traversals with few rays in flight); kept for A/B. */
-#define RTC_FLAG_WAVEFRONT 2
 /* The pixel kernel records how long every wave (8x8 pixel block) took and the next frames of
  * the same view on the same scene handle launch the dearest blocks first (any order gives the
  * same image; a good one shortens the tail of the launch).  This flag renders in plain tile
@@ -175,6 +168,8 @@ typedef struct {
     double kernel_ms;    /* trace kernel time measured with HIP events on its stream (host-buffer calls only) */
     int64_t shadow_rays_culled; /* is_shadowed queries answered without a ray: no cell of the light contributes at
                             that hit (light behind the surface), so the result is the ambient term either way */
+    int64_t pixels_redone; /* pixels whose ray tree found the hit pool full and were traced by the in-lane fallback kernel
+                            (same result; 0 on ordinary frames) */
 } rtc_stats;
 
 typedef struct {

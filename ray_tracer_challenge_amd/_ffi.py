@@ -8,7 +8,7 @@ import weakref
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librtc_hip.so")
+LIB_PATH = os.environ.get("RTC_LIB") or os.path.join(_HERE, "librtc_hip.so")      # RTC_LIB: development builds (tools/build_variant.sh)
 _lib = None
 _P = C.c_void_p
 
@@ -50,7 +50,8 @@ class RenderOpts(C.Structure):
 
 
 class Stats(C.Structure):
-    _fields_ = [("rays", C.c_int64 * 4), ("work", C.c_int64 * 8), ("kernel_ms", C.c_double), ("shadow_rays_culled", C.c_int64)]
+    _fields_ = [("rays", C.c_int64 * 4), ("work", C.c_int64 * 8), ("kernel_ms", C.c_double), ("shadow_rays_culled", C.c_int64),
+                ("pixels_redone", C.c_int64)]
 
 
 class SceneInfo(C.Structure):
@@ -200,11 +201,11 @@ def make_camera(cam):
 
 
 def make_opts(precision="fp64", max_depth=5, tile_size=32, shade_eps=0.0, seed=0, count_work=False, shade_eps_rel=-1.0,
-              wavefront=False, feedback=True):
+              feedback=True):
     bits = {"fp64": 64, "fp32": 32, 64: 64, 32: 32}.get(precision)
     if bits is None:
         raise ValueError("precision must be 'fp64' or 'fp32'")
-    return RenderOpts(bits, int(max_depth), int(tile_size), (1 if count_work else 0) | (2 if wavefront else 0) | (0 if feedback else 8), float(shade_eps), float(shade_eps_rel), int(seed))
+    return RenderOpts(bits, int(max_depth), int(tile_size), (1 if count_work else 0) | (0 if feedback else 8), float(shade_eps), float(shade_eps_rel), int(seed))
 
 
 def make_desc(cs):
@@ -268,9 +269,9 @@ class Scene(object):
         return {k: getattr(out, k) for k, _ in SceneInfo._fields_}
 
     def render(self, cam, precision="fp64", max_depth=5, want_ids=False, stats=None, shade_eps=0.0, seed=0,
-               count_work=False, wavefront=False, feedback=True):
+               count_work=False, feedback=True):
         """-> (rgb (hsize, vsize, 3) f64, ids (hsize, vsize) i32 or None)."""
-        c, o, st = make_camera(cam), make_opts(precision, max_depth, 32, shade_eps, seed, count_work, wavefront=wavefront, feedback=feedback), Stats()
+        c, o, st = make_camera(cam), make_opts(precision, max_depth, 32, shade_eps, seed, count_work, feedback=feedback), Stats()
         rgb = _pinned.empty((c.hsize, c.vsize, 3), np.float64)       # every element is written by the call
         ids = _pinned.empty((c.hsize, c.vsize), np.int32) if want_ids else None
         _check(lib().rtc_render(self.handle, C.byref(c), C.byref(o), rgb.ctypes.data_as(_P),
@@ -291,9 +292,9 @@ class Scene(object):
         return (a[:n.value].tobytes() if clamped else None, b[:n.value].tobytes() if scaled else None)
 
     def render_tiles(self, cam, tile_ids, precision="fp64", max_depth=5, tile_size=32, want_ids=False, stats=None,
-                     shade_eps=0.0, seed=0, wavefront=False, feedback=True):
+                     shade_eps=0.0, seed=0, feedback=True):
         """Compact tiles -> (rgb (n, T, T, 3) [slot][ty][tx], ids (n, T, T) or None)."""
-        c, o, st = make_camera(cam), make_opts(precision, max_depth, tile_size, shade_eps, seed, wavefront=wavefront, feedback=feedback), Stats()
+        c, o, st = make_camera(cam), make_opts(precision, max_depth, tile_size, shade_eps, seed, feedback=feedback), Stats()
         tiles = np.ascontiguousarray(tile_ids, dtype=np.int32)
         n, T = tiles.size, tile_size
         rgb = _pinned.empty((n, T, T, 3), np.float64)
@@ -304,9 +305,9 @@ class Scene(object):
         return rgb, ids
 
     def render_device(self, cam, rgb_ptr, ids_ptr=None, rays_ptr=None, tile_ids_ptr=None, n_tiles=0, precision="fp64",
-                      max_depth=5, tile_size=32, shade_eps=0.0, seed=0, stream=None, count_work=False, wavefront=False, feedback=True):
+                      max_depth=5, tile_size=32, shade_eps=0.0, seed=0, stream=None, count_work=False, feedback=True):
         """Asynchronous launch on device pointers (ints, e.g. torch `tensor.data_ptr()`)."""
-        c, o = make_camera(cam), make_opts(precision, max_depth, tile_size, shade_eps, seed, count_work, wavefront=wavefront, feedback=feedback)
+        c, o = make_camera(cam), make_opts(precision, max_depth, tile_size, shade_eps, seed, count_work, feedback=feedback)
         _check(lib().rtc_render_device(self.handle, C.byref(c), C.byref(o), int(n_tiles), _P(tile_ids_ptr or None),
                                        _P(rgb_ptr), _P(ids_ptr or None), _P(rays_ptr or None), _P(stream or None)))
 
@@ -323,6 +324,7 @@ def _fill_stats(stats, st):
         stats["work"] = [int(v) for v in st.work]
         stats["kernel_ms"] = float(st.kernel_ms)
         stats["shadow_rays_culled"] = int(st.shadow_rays_culled)
+        stats["pixels_redone"] = int(st.pixels_redone)
 
 
 def tiles_for(hsize, vsize, tile_size=32):

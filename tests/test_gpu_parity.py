@@ -7,7 +7,7 @@ import ctypes as C
 import numpy as np
 import pytest
 
-from conftest import frac_off_by_more_than_one, load_golden, load_pack, ppm_levels
+from conftest import frac_off_by_more_than_one, load_golden, load_pack, ppm_levels, small_pool
 from ray_tracer_challenge_amd import _ffi
 from ray_tracer_challenge_amd.canvas import quantize
 from ray_tracer_challenge_amd.compile import compile_scene
@@ -246,23 +246,32 @@ def test_nested_and_blended_patterns_and_nested_csg(oracle_cls):
 
 @pytest.mark.parametrize("name,size", [("cover", None), ("csg_test", (160, 160)), ("shadow_glamour_shot_nojitter", (120, 48)),
                                        ("teapot", None), ("dragons", (480, 192))])
-def test_wavefront_pipeline_matches_single_kernel(name, size, scenes):
-    """RTC_FLAG_WAVEFRONT (the level pipeline: one kernel per bounce level over a ray pool) traces the same rays."""
+def test_full_hit_pool_is_still_exact(name, size, scenes):
+    """The hit pool of the deferred kernels (rtc_deferred.hpp) is sized for ordinary frames; a pixel whose ray tree finds
+    it full is given up and traced in one lane, shadow rays in place, by redo_kernel.  With no secondary records at all
+    (every pixel with a reflection or refraction hit is redone), with a handful, and with the default pool: the same
+    image bit for bit in fp64, the same ids, the same ray counts kind by kind."""
     cam, world, sc = scenes(name)
     if size:
         cam = cam.resized(*size)
-    s1, s2 = {}, {}
+    s1 = {}
     a, ia = sc.render(cam, precision="fp64", want_ids=True, stats=s1)
-    b, ib = sc.render(cam, precision="fp64", want_ids=True, stats=s2, wavefront=True)
-    np.testing.assert_allclose(a, b, rtol=0, atol=1e-9)
-    np.testing.assert_array_equal(ia, ib)
-    assert s1["rays"] == s2["rays"]
-    # fp32: the two forms are compiled separately, so fused multiply-adds fall differently and a ray that
-    # grazes an edge may land on either side of it -- the same gate as fp32 against the reference
-    a, ia = sc.render(cam, precision="fp32", want_ids=True)
-    b, ib = sc.render(cam, precision="fp32", want_ids=True, wavefront=True)
-    assert (np.abs(a - b).max(axis=2) > 1e-4).mean() <= 0.001
-    assert (ia != ib).mean() <= 0.001
+    a32, ia32 = sc.render(cam, precision="fp32", want_ids=True)
+    for records in (0, 512, 4096):
+        with small_pool(records):
+            s2 = {}
+            b, ib = sc.render(cam, precision="fp64", want_ids=True, stats=s2)
+            b32, ib32 = sc.render(cam, precision="fp32", want_ids=True)
+        np.testing.assert_allclose(a, b, rtol=0, atol=1e-12)
+        np.testing.assert_array_equal(ia, ib)
+        assert s1["rays"] == s2["rays"] and s1["shadow_rays_culled"] == s2["shadow_rays_culled"]
+        if name in ("cover", "dragons", "csg_test") and records == 0:
+            assert s2["pixels_redone"] > 0
+        # fp32: the two forms are compiled separately, so fused multiply-adds may fall differently and a ray that
+        # grazes an edge may land on either side of it -- the same gate as fp32 against the reference
+        assert (np.abs(a32 - b32).max(axis=2) > 1e-4).mean() <= 0.001
+        assert (ia32 != ib32).mean() <= 0.001
+    assert s1["pixels_redone"] == 0
 
 
 @pytest.mark.parametrize("name,size", [("cover", None), ("dragons", (480, 192)), ("teapot", None)])
@@ -288,23 +297,6 @@ def test_launch_order_feedback_changes_nothing(name, size, scenes):
     np.testing.assert_array_equal(a, b)
 
 
-def test_level_pipeline_full_pool_is_still_exact(scenes, monkeypatch):
-    """When the ray pool of the level pipeline is full, the rays that found no room are traced in-lane afterwards
-    (lv_redo): same image, same ray counts."""
-    cam, world, sc = scenes("cover")
-    s1, s2, s3 = {}, {}, {}
-    a, ia = sc.render(cam, precision="fp64", want_ids=True, stats=s1)
-    b, ib = sc.render(cam, precision="fp64", want_ids=True, stats=s2, wavefront=True)
-    monkeypatch.setenv("RTC_LEVEL_POOL", "700")          # far fewer than the secondary rays of the frame
-    c, ic = sc.render(cam, precision="fp64", want_ids=True, stats=s3, wavefront=True)
-    monkeypatch.delenv("RTC_LEVEL_POOL")
-    assert sum(s1["rays"][2:]) > 700
-    np.testing.assert_allclose(a, b, rtol=0, atol=1e-9)
-    np.testing.assert_allclose(a, c, rtol=0, atol=1e-9)
-    np.testing.assert_array_equal(ia, ic)
-    assert s1["rays"] == s2["rays"] == s3["rays"]
-
-
 def test_jittered_area_light(scenes):
     """shadow_glamour_shot.yml as shipped (jitter: true).  The reference draws from Python's global RNG in a
     process-timing-dependent order, so there is no image to compare with; the kernel's counter-based samples must be
@@ -317,7 +309,8 @@ def test_jittered_area_light(scenes):
     a, ids_a = sj.render(cam, precision="fp64", want_ids=True, seed=1)
     b, _ = sj.render(cam, precision="fp64", seed=1)
     c, _ = sj.render(cam, precision="fp64", seed=2)
-    lv, _ = sj.render(cam, precision="fp64", seed=1, wavefront=True)
+    with small_pool(0):
+        lv, _ = sj.render(cam, precision="fp64", seed=1)
     np.testing.assert_array_equal(a, b)
     np.testing.assert_allclose(a, lv, rtol=0, atol=1e-9)
     np.testing.assert_array_equal(ids_a, ids_plain)
@@ -380,7 +373,7 @@ def _same_image(a, b, ia, ib):
 @pytest.mark.parametrize("name,size", [("teapot", None), ("dragons", (480, 192)), ("cover", None)])
 def test_triangle_bvh_built_on_the_gpu(name, size):
     """rtc_scene_build_bvh_device: same image as with the host-built tree, in both precisions, through the
-    default kernel and the level pipeline; scenes without triangles are left alone."""
+    kernels; scenes without triangles are left alone."""
     cam, world, _ = load_pack(name)
     if size:
         cam = cam.resized(*size)
@@ -393,9 +386,7 @@ def test_triangle_bvh_built_on_the_gpu(name, size):
         after = sc.info()
         b, ib = sc.render(cam, precision="fp64", want_ids=True, stats=s1)
         b32, ib32 = sc.render(cam, precision="fp32", want_ids=True)
-        c, ic = sc.render(cam, precision="fp64", want_ids=True, wavefront=True)
         _same_image(a, b, ia, ib)
-        _same_image(a, c, ia, ic)
         assert frac_off_by_more_than_one(b32, a) <= 0.001
         assert abs(sum(s0["rays"]) - sum(s1["rays"])) <= 1e-4 * sum(s0["rays"])
         if name == "cover":
@@ -438,8 +429,8 @@ def test_moving_triangles_rebuild_on_the_gpu(refit):
 
 def test_refit_follows_a_deforming_mesh():
     """rtc_scene_refit_triangles on both kinds of tree: every triangle of the teapot displaced by its own amount (a
-    deformation, not a rigid motion), refitted twice in a row (host SAH tree, then the GPU-built tree), both precisions
-    and the level pipeline, against a scene created from the deformed rows."""
+    deformation, not a rigid motion), refitted twice in a row (host SAH tree, then the GPU-built tree), both precisions,
+    against a scene created from the deformed rows."""
     cam, world, _ = load_pack("teapot")
     cam = cam.resized(200, 100)
     cs = compile_scene(world)
@@ -479,9 +470,7 @@ def test_refit_follows_a_deforming_mesh():
         assert frac_off_by_more_than_one(a32, want1) <= 0.001
         sc.update_triangles(g2, cs.arrays["tri_norm"], refit=True)            # and again, further
         b, ib = sc.render(cam, precision="fp64", want_ids=True)
-        c, ic = sc.render(cam, precision="fp64", want_ids=True, wavefront=True)
         _same_image(want2, b, ids2, ib)
-        _same_image(want2, c, ids2, ic)
         sc.build_bvh_on_device()                                               # GPU-built tree over g2 ...
         sc.update_triangles(g1, cs.arrays["tri_norm"], refit=True)            # ... refitted back to g1
         d, idd = sc.render(cam, precision="fp64", want_ids=True)

@@ -10,7 +10,7 @@ md = s[s.index("amdhsa.kernels"):]
 for blk in md.split("  - .agpr_count:")[1:]:
     g = lambda k: re.search(r"\.%s:\s+(\S+)" % k, blk).group(1)
     n = g("name")
-    m = re.search(r"(trace_kernel|lv_primary|lv_level)I(\w+?)EEv", n)
+    m = re.search(r"(trace_kernel|shadow_kernel|redo_kernel|resolve_kernel)I(\w+?)EEv", n)
     if m:
         print("%-15s %-10s" % m.groups(), "vgpr", g("vgpr_count"), "vspill", g("vgpr_spill_count"),
-              "sspill", g("sgpr_spill_count"), "scratch", g("private_segment_fixed_size"))
+              "sgpr", g("sgpr_count"), "sspill", g("sgpr_spill_count"), "lds", g("group_segment_fixed_size"), "scratch", g("private_segment_fixed_size"))

@@ -8,8 +8,8 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 run() {
   n=$1; shift
-  timeout -s KILL 120 rocprofv3 --pmc "$@" -d $OUT/$n -o pmc -- python3 $R/tools/one_scene.py $S $W $H $P mega 3 > /dev/null 2> $OUT/$n.err || exit 1
-  python3 $R/tools/pmc_dump.py $OUT/$n/pmc_results.db 1 >> $OUT/summary.txt
+  timeout -s KILL 120 rocprofv3 --pmc "$@" -d $OUT/$n -o pmc -- python3 $R/tools/one_scene.py $S $W $H $P 3 > /dev/null 2> $OUT/$n.err || exit 1
+  python3 $R/tools/pmc_dump.py $OUT/$n/pmc_results.db 4 >> $OUT/summary.txt
 }
 : > $OUT/summary.txt
 run ic1 SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE SQ_IFETCH SQ_INSTS_BRANCH SQ_WAVE_CYCLES SQ_BUSY_CYCLES

@@ -8,8 +8,8 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 run() { # name, counters...
   n=$1; shift
-  timeout -s KILL 120 rocprofv3 --pmc "$@" -d $OUT/$n -o pmc -- python3 $R/tools/one_scene.py $S $W $H $P mega 3 > /dev/null 2> $OUT/$n.err || exit 1
-  python3 $R/tools/pmc_dump.py $OUT/$n/pmc_results.db 1 >> $OUT/summary.txt
+  timeout -s KILL 120 rocprofv3 --pmc "$@" -d $OUT/$n -o pmc -- python3 $R/tools/one_scene.py $S $W $H $P 3 > /dev/null 2> $OUT/$n.err || exit 1
+  python3 $R/tools/pmc_dump.py $OUT/$n/pmc_results.db 4 >> $OUT/summary.txt
 }
 : > $OUT/summary.txt
 run sq1 SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_INSTS_FLAT
