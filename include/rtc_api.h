@@ -168,8 +168,6 @@ typedef struct {
     double kernel_ms;    /* trace kernel time measured with HIP events on its stream (host-buffer calls only) */
     int64_t shadow_rays_culled; /* is_shadowed queries answered without a ray: no cell of the light contributes at
                             that hit (light behind the surface), so the result is the ambient term either way */
-    int64_t pixels_redone; /* pixels whose ray tree found the hit pool full and were traced by the in-lane fallback kernel
-                            (same result; 0 on ordinary frames) */
 } rtc_stats;
 
 typedef struct {

@@ -50,8 +50,7 @@ class RenderOpts(C.Structure):
 
 
 class Stats(C.Structure):
-    _fields_ = [("rays", C.c_int64 * 4), ("work", C.c_int64 * 8), ("kernel_ms", C.c_double), ("shadow_rays_culled", C.c_int64),
-                ("pixels_redone", C.c_int64)]
+    _fields_ = [("rays", C.c_int64 * 4), ("work", C.c_int64 * 8), ("kernel_ms", C.c_double), ("shadow_rays_culled", C.c_int64)]
 
 
 class SceneInfo(C.Structure):
@@ -324,7 +323,6 @@ def _fill_stats(stats, st):
         stats["work"] = [int(v) for v in st.work]
         stats["kernel_ms"] = float(st.kernel_ms)
         stats["shadow_rays_culled"] = int(st.shadow_rays_culled)
-        stats["pixels_redone"] = int(st.pixels_redone)
 
 
 def tiles_for(hsize, vsize, tile_size=32):

@@ -17,7 +17,6 @@
 #include "../../include/rtc_api.h"
 #include "rtc_bvh.hpp"
 #include "rtc_device.hpp"
-#include "rtc_deferred.hpp"
 #include "rtc_lbvh_device.hpp"
 #include <rocprim/rocprim.hpp>
 
@@ -44,26 +43,8 @@ int fail(int code, const char* fmt, ...) {
 // ---------------------------------------------------------------------------------------------
 // kernels
 // ---------------------------------------------------------------------------------------------
-// waves per SIMD the kernels are compiled for (register budget = 512 / waves); CSG variants carry per-lane hit lists
-#ifndef RTC_TRACE_WAVES_F64
-#define RTC_TRACE_WAVES_F64 4
-#endif
-#ifndef RTC_TRACE_WAVES_F32
-#define RTC_TRACE_WAVES_F32 5
-#endif
-#ifndef RTC_SHADOW_WAVES_F64
-#define RTC_SHADOW_WAVES_F64 5
-#endif
-#ifndef RTC_SHADOW_WAVES_F32
-#define RTC_SHADOW_WAVES_F32 5
-#endif
-#define RTC_TRACE_WAVES(R, CSG) ((CSG) ? 2 : sizeof(R) == 8 ? RTC_TRACE_WAVES_F64 : RTC_TRACE_WAVES_F32)
-#define RTC_SHADOW_WAVES(R, CSG) ((CSG) ? 2 : sizeof(R) == 8 ? RTC_SHADOW_WAVES_F64 : RTC_SHADOW_WAVES_F32)
-#define RTC_REDO_WAVES(R, CSG) ((CSG) ? 2 : sizeof(R) == 8 ? RTC_WAVES_F64 : RTC_WAVES_F32)
-
-// one lane = one pixel, camera ray to colour: the pixel's whole ray tree in the lane, shadow rays traced in place
 template <class R, bool PROF, bool CSG>
-__global__ __launch_bounds__(RTC_BLOCK, RTC_REDO_WAVES(R, CSG)) void fused_kernel(rtc::DScene<R> S, rtc::DCamera<R> cam, rtc::DFrame F, R shade_eps, R shade_eps_rel) {
+__global__ __launch_bounds__(RTC_BLOCK, (CSG ? 2 : sizeof(R) == 8 ? RTC_WAVES_F64 : RTC_WAVES_F32)) void trace_kernel(rtc::DScene<R> S, rtc::DCamera<R> cam, rtc::DFrame F, R shade_eps, R shade_eps_rel) {
     __shared__ int s_stack[RTC_BVH_STACK * RTC_BLOCK];
     int* stack = s_stack + threadIdx.x;
     const int lane = threadIdx.x & 63;
@@ -71,186 +52,27 @@ __global__ __launch_bounds__(RTC_BLOCK, RTC_REDO_WAVES(R, CSG)) void fused_kerne
     rtc::zero_counters(cnt);
     const long long t_start = F.cost ? (long long)wall_clock64() : 0;
     bool lane_on;
-    const long long unit = rtc::entry_unit(F, rtc::wave_entry(F), lane, lane_on);
+    const long long unit = rtc::wave_unit(F, lane_on);
     int x, y;
     size_t o;
     if (unit >= 0 && lane_on && rtc::work_pixel(F, cam.hsize, cam.vsize, unit * 64 + lane, x, y, o)) {
         rtc::Ray<R> ray = rtc::ray_for_pixel(cam, x, y);
         cnt.c[0] = 1;
         int hit_leaf;
-        rtc::V3<R> c = rtc::trace_pixel(S, ray, F.max_depth, shade_eps, shade_eps_rel, stack, cnt, F.seed, (uint32_t)(y * cam.hsize + x), hit_leaf);
+#ifdef RTC_TIMELINE
+        long long tl_start = wall_clock64();
+#endif
+        rtc::V3<R> c = rtc::trace_pixel(S, ray, F.max_depth, shade_eps, shade_eps_rel, stack, cnt, F.seed,
+                                        (uint32_t)(y * cam.hsize + x), hit_leaf);
+#ifdef RTC_TIMELINE   /* development build only (tools/timeline.py): start/end ticks (100 MHz) instead of the colour */
+        c.x = (R)(double)(tl_start & 0xFFFFFFFFFFLL); c.y = (R)(double)(wall_clock64() & 0xFFFFFFFFFFLL); c.z = R(0);
+#endif
         F.rgb[3 * o] = (double)c.x; F.rgb[3 * o + 1] = (double)c.y; F.rgb[3 * o + 2] = (double)c.z;
         if (F.hit_id) F.hit_id[o] = hit_leaf;
     }
     if (F.cost && unit >= 0 && lane == 0) {
         long long dt = (long long)wall_clock64() - t_start;
         atomicAdd(F.cost + unit, (uint32_t)(dt < 0 ? 0 : dt > 0x0FFFFFFFLL ? 0x0FFFFFFFLL : dt));
-    }
-    rtc::flush_counters(cnt, F, reinterpret_cast<unsigned int*>(s_stack));
-}
-
-// rtc_deferred.hpp: one lane = one pixel, the pixel's tree of nearest-hit queries; shaded hits -> records
-template <class R, bool PROF, bool CSG>
-__global__ __launch_bounds__(RTC_BLOCK, RTC_TRACE_WAVES(R, CSG)) void trace_kernel(rtc::DScene<R> S, rtc::DCamera<R> cam, rtc::DFrame F, rtc::HitPool<R> P,
-                                                                                   R shade_eps, R shade_eps_rel) {
-    __shared__ int s_stack[RTC_BVH_STACK * RTC_BLOCK];
-    int* stack = s_stack + threadIdx.x;
-    const int lane = threadIdx.x & 63;
-    rtc::Counters<PROF, CSG> cnt;
-    rtc::zero_counters(cnt);
-    const long long t_start = F.cost ? (long long)wall_clock64() : 0;
-    if (blockIdx.x == 0 && threadIdx.x < sizeof(rtc::PoolCtrl) / 4) reinterpret_cast<uint32_t*>(P.ctrl_next)[threadIdx.x] = 0u;
-    bool lane_on;
-    const long long unit = rtc::entry_unit(F, rtc::wave_entry(F), lane, lane_on);
-    const int slot = blockIdx.x * RTC_BLOCK + threadIdx.x;
-    int state = 0;
-    int x, y;
-    size_t o;
-    if (unit >= 0 && lane_on && rtc::work_pixel(F, cam.hsize, cam.vsize, unit * 64 + lane, x, y, o)) {
-        rtc::Ray<R> ray = rtc::ray_for_pixel(cam, x, y);
-        cnt.c[0] = 1;
-        int hit_leaf;
-        state = rtc::trace_tree_deferred(S, ray, F.max_depth, shade_eps, shade_eps_rel, stack, cnt, F.seed, (uint32_t)(y * cam.hsize + x), slot, P, hit_leaf);
-        if (F.hit_id) F.hit_id[o] = hit_leaf;
-    }
-    P.state[slot] = state;
-    if (F.cost && unit >= 0 && lane == 0) {
-        long long dt = (long long)wall_clock64() - t_start;
-        atomicAdd(F.cost + unit, (uint32_t)(dt < 0 ? 0 : dt > 0x0FFFFFFFLL ? 0x0FFFFFFFLL : dt));
-    }
-    rtc::flush_counters(cnt, F, reinterpret_cast<unsigned int*>(s_stack));
-}
-
-// is_shadowed (renderer.py:552-560) for every pending (record, light, cell group).  A wave takes RTC_SHADOW_ROWS
-// consecutive rows of 64 candidates (records of one light and cell group), ballots the pending ones, compacts them
-// into a wave-local queue in LDS and traces whole wavefronts of any-hit rays.  The grid covers the pool's whole
-// capacity (the host does not know how many records the trace kernel took); waves past the used part leave at once,
-// and the hardware dispatcher balances the rest.
-template <class R, bool PROF, bool CSG>
-__global__ __launch_bounds__(RTC_BLOCK, RTC_SHADOW_WAVES(R, CSG)) void shadow_kernel(rtc::DScene<R> S, rtc::DFrame F, rtc::HitPool<R> P, int rows_per_combo) {
-    __shared__ int s_stack[RTC_BVH_STACK * RTC_BLOCK];
-    __shared__ int s_queue[RTC_BLOCK / 64][128];
-    int* stack = s_stack + threadIdx.x;
-    const int lane = threadIdx.x & 63;
-    const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    volatile int* queue = s_queue[wib];
-    rtc::Counters<PROF, CSG> cnt;
-    rtc::zero_counters(cnt);
-    // this wave's rows: [row0, row0 + RTC_SHADOW_ROWS) of combo (light, cell group); blockIdx.y = combo
-    int l = 0, g = (int)blockIdx.y;
-    for (; l < S.n_lights - 1; l++) {
-        const int ng = rtc::light_groups(rtc::light_shape(S, l).samples, P.cells_per_group);
-        if (g < ng) break;
-        g -= ng;
-    }
-    const int row0 = ((int)blockIdx.x * (RTC_BLOCK / 64) + wib) * RTC_SHADOW_ROWS;
-    const size_t cap = (size_t)P.cap;
-    const unsigned long long below = (1ULL << lane) - 1ULL;
-    const rtc::LightShape ls = rtc::light_shape(S, l);
-    const int k0 = g * P.cells_per_group, k1 = k0 + P.cells_per_group < ls.samples ? k0 + P.cells_per_group : ls.samples;
-    int qn = 0, j = 0;
-    while (true) {
-        while (qn < 64 && j < RTC_SHADOW_ROWS && row0 + j < rows_per_combo) {
-            const int r = (row0 + j) * 64 + lane;
-            bool valid;
-            if (r < P.n_slots) valid = P.state[r] == 1;
-            else if (r < P.cap && P.sub_cap > 0) {
-                const int s = (r - P.n_slots) / P.sub_cap, idx = (r - P.n_slots) - s * P.sub_cap;
-                valid = s < RTC_POOL_SHARDS && (uint32_t)idx < P.ctrl->count[s];
-            } else valid = false;
-            if (valid) valid = P.lit[(size_t)l * cap + r] < 0;
-            const unsigned long long mask = __ballot(valid);
-            if (valid) queue[qn + __popcll(mask & below)] = r;
-            qn += __popcll(mask);
-            j++;
-        }
-        if (qn == 0) break;
-        const int take = qn < 64 ? qn : 64;
-        qn -= take;
-        __builtin_amdgcn_wave_barrier();
-        if (lane < take) {
-            const int r = queue[qn + lane];
-            const R* rec = P.rec + r;
-            const rtc::V3<R> over_point = rtc::mk<R>(rec[(rtc::REC_OVER + 0) * cap], rec[(rtc::REC_OVER + 1) * cap], rec[(rtc::REC_OVER + 2) * cap]);
-            const uint32_t pixel = P.tag[r], path = P.tag[cap + r];
-            int lit = 0;
-#ifdef RTC_SHADOW_NOTRACE   /* development: everything but the traversal */
-            lit = (k1 - k0) * (over_point.x != R(12345) && pixel + path != 0xFFFFFFFFu ? 1 : 0);
-#else
-            for (int k = k0; k < k1; k++) {
-                const int u = k % ls.usteps, v = k / ls.usteps;
-                if (!rtc::is_shadowed(S, rtc::light_sample<R>(S, l, ls, u, v, F.seed, pixel, path, 0), over_point, stack, cnt)) lit++;
-            }
-#endif
-            if (lit) atomicAdd(&P.lit[(size_t)l * cap + r], lit);
-        }
-        __builtin_amdgcn_wave_barrier();
-    }
-    rtc::flush_counters(cnt, F, reinterpret_cast<unsigned int*>(s_stack));
-}
-
-// one lane per pixel slot: the pixel's colour from its records, in the order its tree produced them
-template <class R>
-__global__ __launch_bounds__(RTC_BLOCK) void resolve_kernel(rtc::DScene<R> S, int hsize, int vsize, rtc::DFrame F, rtc::HitPool<R> P) {
-    const int lane = threadIdx.x & 63;
-    bool lane_on;
-    const long long unit = rtc::entry_unit(F, rtc::wave_entry(F), lane, lane_on);
-    const int slot = blockIdx.x * RTC_BLOCK + threadIdx.x;
-    int x, y;
-    size_t o;
-    if (unit < 0 || !lane_on || !rtc::work_pixel(F, hsize, vsize, unit * 64 + lane, x, y, o)) return;
-    const int state = P.state[slot];
-    if (state == 2) return;                       // redo_kernel writes this pixel
-    rtc::V3<R> c = rtc::mk<R>(0, 0, 0);
-    if (state == 1) c = rtc::resolve_pixel(S, P, slot);
-    F.rgb[3 * o] = (double)c.x; F.rgb[3 * o + 1] = (double)c.y; F.rgb[3 * o + 2] = (double)c.z;
-}
-
-// the pixels trace_kernel gave up (hit pool full): the whole tree in one lane, shadow rays traced in place --
-// color_at as the reference recurses through it; waves compact the given-up slots like the shadow kernel does
-template <class R, bool PROF, bool CSG>
-__global__ __launch_bounds__(RTC_BLOCK, RTC_REDO_WAVES(R, CSG)) void redo_kernel(rtc::DScene<R> S, rtc::DCamera<R> cam, rtc::DFrame F, rtc::HitPool<R> P,
-                                                                                 R shade_eps, R shade_eps_rel) {
-    if (P.ctrl->failed == 0) return;
-    __shared__ int s_stack[RTC_BVH_STACK * RTC_BLOCK];
-    __shared__ int s_queue[RTC_BLOCK / 64][128];
-    int* stack = s_stack + threadIdx.x;
-    const int lane = threadIdx.x & 63;
-    const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    volatile int* queue = s_queue[wib];
-    rtc::Counters<PROF, CSG> cnt;
-    rtc::zero_counters(cnt);
-    const int n_rows = (P.n_slots + 63) / 64, n_waves = (int)gridDim.x * (RTC_BLOCK / 64);
-    const unsigned long long below = (1ULL << lane) - 1ULL;
-    int j = (int)blockIdx.x * (RTC_BLOCK / 64) + wib, qn = 0;
-    while (true) {
-        while (qn < 64 && j < n_rows) {
-            const int slot = j * 64 + lane;
-            const bool valid = slot < P.n_slots && P.state[slot] == 2;
-            const unsigned long long mask = __ballot(valid);
-            if (valid) queue[qn + __popcll(mask & below)] = slot;
-            qn += __popcll(mask);
-            j += n_waves;
-        }
-        if (qn == 0) break;
-        const int take = qn < 64 ? qn : 64;
-        qn -= take;
-        __builtin_amdgcn_wave_barrier();
-        if (lane == 0 && F.redone) atomicAdd(F.redone, (unsigned long long)take);
-        if (lane < take) {
-            const int slot = queue[qn + lane];
-            bool lane_on;
-            const long long unit = rtc::entry_unit(F, F.entry0 + (slot >> 6), slot & 63, lane_on);
-            int x, y;
-            size_t o;
-            if (unit >= 0 && lane_on && rtc::work_pixel(F, cam.hsize, cam.vsize, unit * 64 + (slot & 63), x, y, o)) {
-                rtc::Ray<R> ray = rtc::ray_for_pixel(cam, x, y);
-                int hit_leaf;
-                rtc::V3<R> c = rtc::trace_pixel(S, ray, F.max_depth, shade_eps, shade_eps_rel, stack, cnt, F.seed, (uint32_t)(y * cam.hsize + x), hit_leaf);
-                F.rgb[3 * o] = (double)c.x; F.rgb[3 * o + 1] = (double)c.y; F.rgb[3 * o + 2] = (double)c.z;
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
     }
     rtc::flush_counters(cnt, F, reinterpret_cast<unsigned int*>(s_stack));
 }
@@ -429,18 +251,16 @@ template <class R> std::vector<R> cast_vec(const double* p, size_t n) {
     return v;
 }
 
-// boxes padded outward so that neither rounding in the compiler nor in the fp32 slab test can reject a leaf the
-// leaf test itself would accept: 2e-5 relative, at least 2e-5 absolute and at least `pad_abs` (4e-7 of the largest
-// coordinate of the scene: the fp32 box arithmetic works on positions relative to the ray's entry into the tree)
-#define RTC_PAD_OF_EXTENT 4e-7
-template <class R> std::vector<R> pad_boxes(const std::vector<double>& box, double pad_abs) {
+// boxes padded outward so that neither rounding in the compiler nor in the slab test can
+// reject a leaf the leaf test itself would accept
+template <class R> std::vector<R> pad_boxes(const std::vector<double>& box) {
     const double rel = sizeof(R) == 4 ? 2e-5 : 1e-9;
     std::vector<R> out(box.size());
     for (size_t i = 0; i < box.size(); i++) {
         bool is_hi = (i % 6) >= 3;
         double v = box[i];
         if (std::isfinite(v)) {
-            double pad = std::max(rel * std::max(1.0, std::fabs(v)), pad_abs);
+            double pad = rel * std::max(1.0, std::fabs(v));
             v = is_hi ? v + pad : v - pad;
             R r = (R)v;
             if (is_hi && (double)r < v) r = std::nextafter(r, std::numeric_limits<R>::infinity());
@@ -453,20 +273,9 @@ template <class R> std::vector<R> pad_boxes(const std::vector<double>& box, doub
     return out;
 }
 
-// the tree's grid (rtc_qnode.hpp) from the root node's two (padded fp32) child boxes
-rtc::TreeGrid grid_of_root(const float* box12, int32_t c0, int32_t c1) {
-    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-    const int32_t c[2] = {c0, c1};
-    for (int side = 0; side < 2; side++) {
-        if (c[side] == RTC_EMPTY_CHILD) continue;
-        for (int k = 0; k < 3; k++) { lo[k] = std::min(lo[k], box12[6 * side + k]); hi[k] = std::max(hi[k], box12[6 * side + 3 + k]); }
-    }
-    return rtc::make_tree_grid(lo, hi);
-}
-
 }  // namespace
 
-// What one render call needs beyond the scene: the launch-order feedback of its view and the hit pool.  A scene
+// What one render call needs beyond the scene: the launch-order feedback of its view.  A scene
 // handle keeps a list of these; a call takes one that is free -- last used on the call's own stream (stream order
 // protects it) or finished (its event has completed) -- so calls from several host threads on several streams
 // never share one.
@@ -483,13 +292,8 @@ struct Workspace {
     // what the current order was measured on, and how many frames of it have been sorted: the order is rebuilt
     // after the first two frames of a view (the second one measured under the new order) and then kept
     FbKey fb_key{}; int fb_age = 0;
-    // hit pool (rtc_deferred.hpp): one allocation carved into the SoA arrays of a launch
-    void* pool = nullptr; size_t pool_bytes = 0;
-    rtc::PoolCtrl* ctrl = nullptr; int ctrl_cur = 0;       // two counter blocks: a frame's trace kernel zeroes the next frame's
     void release() {
         fb_mem.release();
-        if (pool) (void)hipFree(pool);
-        if (ctrl) (void)hipFree(ctrl);
         if (fb_used_host) (void)hipHostFree(fb_used_host);
         if (fb_used_event) (void)hipEventDestroy(fb_used_event);
         if (done) (void)hipEventDestroy(done);
@@ -505,21 +309,16 @@ struct rtc_scene {
     rtc::DScene<double> d64;
     rtc::DScene<float> d32;
     bool has_jitter = false, has_csg = false;
-    int n_lights = 0;
-    std::vector<int> light_samples;   // cells of each light (1 for a point light)
     std::mutex ws_mutex;      // guards the workspace list
     std::vector<Workspace*> workspaces;
     int n_cus = 0;
     bool has_secondary = false;   // some material reflects or refracts
-    bool branching = false;       // some material does both: a ray tree can have 2^(depth+1) - 1 rays, otherwise depth + 1
     // what a GPU rebuild of the triangle BVH needs: the triangle items (prim codes, item order) and the
     // arena that owns the current triangle BVH (nodes, BVH-ordered rows in both precisions, leaf ids)
     int32_t* d_titems = nullptr; int n_titems = 0; long long n_tris = 0;
     DeviceArena tbvh_mem;
     // for refits (same arena): triangle row at each BVH position, parent link of each node, arrival counters
     int32_t* d_tb_row = nullptr; int32_t* d_tparent = nullptr; uint32_t* d_tarrived = nullptr;
-    rtc::BvhNode* d_tbuild = nullptr;   // the triangle BVH in the builders' fp32 form (refits update it, the kernels walk the QNodes made from it)
-    double pad_abs = 0;                 // RTC_PAD_OF_EXTENT x the largest coordinate the scene had when its boxes were made
     // device-side frame, hit ids, counters and tile list of the host-buffer entry points, kept between calls
     std::mutex out_mutex;
     double* out_rgb = nullptr; int32_t* out_id = nullptr; int64_t* out_rays = nullptr; int32_t* out_tiles = nullptr;
@@ -531,7 +330,7 @@ struct rtc_scene {
 namespace {
 
 template <class R>
-int upload_real(const rtc_scene_desc& d, DeviceArena& A, rtc::DScene<R>& S) {
+int upload_real(const rtc_scene_desc& d, const std::vector<double>& node_box, DeviceArena& A, rtc::DScene<R>& S) {
 #define UP_REAL(field, src, count)                                             \
     do {                                                                       \
         std::vector<R> tmp_ = cast_vec<R>((src), (size_t)(count));             \
@@ -551,6 +350,7 @@ int upload_real(const rtc_scene_desc& d, DeviceArena& A, rtc::DScene<R>& S) {
     UP_REAL(light_geom, d.light_geom, 9 * (size_t)d.n_lights);
     UP_REAL(light_intensity, d.light_intensity, 3 * (size_t)d.n_lights);
 #undef UP_REAL
+    (void)node_box;
     return 0;
 }
 
@@ -773,40 +573,26 @@ int create_impl(const rtc_scene_desc& d, rtc_scene* sc) {
     CP(tex_off); CP(tex_w); CP(tex_h); CP(tex_data); CP(n_lights); CP(refraction_matters); CP(light_type); CP(light_steps);
 #undef CP
     {
-        double max_abs = 0;
-        for (const rtc::Bvh* b : {&bvh, &tbvh})
-            for (double v : b->box) if (std::isfinite(v)) max_abs = std::max(max_abs, std::fabs(v));
-        sc->pad_abs = RTC_PAD_OF_EXTENT * max_abs;
-        auto pack = [&](const rtc::Bvh& b, rtc::TreeGrid& G, std::vector<rtc::BvhNode>& build) {
-            std::vector<float> boxes = pad_boxes<float>(b.box, sc->pad_abs);
-            build.resize((size_t)b.n_nodes());
-            std::vector<rtc::QNode> out((size_t)b.n_nodes());
-            memset(&G, 0, sizeof(G));
-            if (b.n_nodes() > 0) G = grid_of_root(&boxes[0], b.child[0], b.child[1]);
+        auto pack = [](const rtc::Bvh& b) {
+            std::vector<float> boxes = pad_boxes<float>(b.box);
+            std::vector<rtc::BvhNode> out((size_t)b.n_nodes());
             for (int i = 0; i < b.n_nodes(); i++) {
-                memcpy(build[i].box, &boxes[12 * (size_t)i], 12 * sizeof(float));
-                build[i].child[0] = b.child[2 * (size_t)i]; build[i].child[1] = b.child[2 * (size_t)i + 1];
-                build[i].pad[0] = build[i].pad[1] = 0;
-                rtc::qnode_encode(build[i].box, build[i].child[0], build[i].child[1], RTC_EMPTY_CHILD, G, out[i]);
+                memcpy(out[i].box, &boxes[12 * (size_t)i], 12 * sizeof(float));
+                out[i].child[0] = b.child[2 * (size_t)i]; out[i].child[1] = b.child[2 * (size_t)i + 1];
+                out[i].pad[0] = out[i].pad[1] = 0;
             }
             return out;
         };
-        std::vector<rtc::BvhNode> ob, tb;
-        std::vector<rtc::QNode> on = pack(bvh, S.ogrid, ob), tn = pack(tbvh, S.tgrid, tb);
+        std::vector<rtc::BvhNode> on = pack(bvh), tn = pack(tbvh);
         if (int rc = A.upload(on.data(), on.size(), &S.nodes)) return rc;
         if (int rc = sc->tbvh_mem.upload(tn.data(), tn.size(), &S.tnodes)) return rc;
-        {
-            const rtc::BvhNode* p_build = nullptr;
-            if (int rc = sc->tbvh_mem.upload(tb.data(), tb.size(), &p_build)) return rc;
-            sc->d_tbuild = const_cast<rtc::BvhNode*>(p_build);
-        }
-        F.nodes = S.nodes; F.tnodes = S.tnodes; F.ogrid = S.ogrid; F.tgrid = S.tgrid;
+        F.nodes = S.nodes; F.tnodes = S.tnodes;
         if (int rc = sc->tbvh_mem.upload(tb_geom.data(), tb_geom.size(), &sc->d64.tb_geom)) return rc;
         std::vector<float> g32 = cast_vec<float>(tb_geom.data(), tb_geom.size());
         if (int rc = sc->tbvh_mem.upload(g32.data(), g32.size(), &sc->d32.tb_geom)) return rc;
     }
-    if (int rc = upload_real<double>(d, sc->mem64, sc->d64)) return rc;
-    if (int rc = upload_real<float>(d, sc->mem32, sc->d32)) return rc;
+    if (int rc = upload_real<double>(d, bvh.box, sc->mem64, sc->d64)) return rc;
+    if (int rc = upload_real<float>(d, bvh.box, sc->mem32, sc->d32)) return rc;
     if ((sc->d64.n_bvh_nodes > 0 && (!sc->d64.nodes || !sc->d64.bvh_prims || !sc->d32.nodes)) ||
         (sc->d64.n_tnodes > 0 && (!sc->d64.tnodes || !sc->d64.tb_geom || !sc->d64.tb_leaf || !sc->d32.tnodes || !sc->d32.tb_geom)))
         return fail(RTC_ERR_HIP, "internal: BVH arrays missing on the device");
@@ -814,15 +600,9 @@ int create_impl(const rtc_scene_desc& d, rtc_scene* sc) {
     for (int i = 0; i < d.n_instr; i++)
         if (d.instr[2 * (size_t)i] == RTC_OP_PERTURB) sc->has_csg = true;      // the noise code lives in the same kernel variants
     for (int i = 0; i < d.n_materials; i++)
-    {
         if (d.mat[10 * (size_t)i + 7] != 0.0 || d.mat[10 * (size_t)i + 8] != 0.0) sc->has_secondary = true;
-        if (d.mat[10 * (size_t)i + 7] != 0.0 && d.mat[10 * (size_t)i + 8] != 0.0) sc->branching = true;
-    }
-    sc->n_lights = d.n_lights;
-    sc->light_samples.assign((size_t)d.n_lights, 1);
     for (int i = 0; i < d.n_lights; i++) {
         if (d.light_type[i] == 1 && d.light_steps[3 * i + 2]) sc->has_jitter = true;
-        if (d.light_type[i] == 1) sc->light_samples[i] = d.light_steps[3 * i] * d.light_steps[3 * i + 1];
     }
     return 0;
 }
@@ -852,23 +632,6 @@ int check_render_args(const rtc_scene* scene, const rtc_camera* cam, const rtc_r
     return 0;
 }
 
-// After a GPU build or refit: the root's boxes come back to the host (48 bytes), the tree's grid is made from them
-// and the nodes the kernels walk are quantised from the builders' fp32 nodes.  *max_abs = largest coordinate of the tree.
-int quantize_triangle_tree(rtc_scene* sc, const rtc::BvhNode* build, int n_nodes, rtc::QNode* out, double* max_abs) {
-    rtc::BvhNode root;
-    HIP_TRY(hipMemcpy(&root, build, sizeof(root), hipMemcpyDeviceToHost));          // also waits for the builders
-    *max_abs = 0;
-    for (int side = 0; side < 2; side++)
-        if (root.child[side] != RTC_EMPTY_CHILD)
-            for (int a = 0; a < 6; a++) *max_abs = std::max(*max_abs, (double)std::fabs(root.box[6 * side + a]));
-    if (!std::isfinite(*max_abs)) return fail(RTC_ERR_INVALID, "triangle rows are not finite");
-    const rtc::TreeGrid G = grid_of_root(root.box, root.child[0], root.child[1]);
-    hipLaunchKernelGGL(rtc::bvh_quantize_kernel, dim3((unsigned)((n_nodes + 255) / 256)), dim3(256), 0, nullptr, n_nodes, build, G, out);
-    HIP_TRY(hipGetLastError());
-    sc->d64.tgrid = sc->d32.tgrid = G;
-    return 0;
-}
-
 // The triangle BVH rebuilt on the GPU from the resident triangle rows (rtc_lbvh.hpp).  Builds into
 // fresh buffers and swaps them in only if the tree fits the traversal stack.
 int rebuild_triangle_bvh_device(rtc_scene* sc) {
@@ -881,11 +644,11 @@ int rebuild_triangle_bvh_device(rtc_scene* sc) {
         A.ptrs.push_back(*out); A.bytes += bytes;
         return 0;
     };
-    void *p_nodes, *p_qnodes, *p_g64, *p_g32, *p_leaf, *p_row, *p_arr2, *p_boxes, *p_bounds, *p_keys, *p_sorted, *p_idx, *p_sidx, *p_lkeys, *p_pin, *p_pleaf, *p_arr, *p_deep, *p_tmp = nullptr;
+    void *p_nodes, *p_g64, *p_g32, *p_leaf, *p_row, *p_arr2, *p_boxes, *p_bounds, *p_keys, *p_sorted, *p_idx, *p_sidx, *p_lkeys, *p_pin, *p_pleaf, *p_arr, *p_deep, *p_tmp = nullptr;
     const size_t n_nodes = (size_t)std::max(1, n_leaves - 1);
     int rc = 0;
     auto bail = [&](int code) { fresh.release(); temp.release(); return code; };
-    if ((rc = alloc(fresh, n_nodes * sizeof(rtc::BvhNode), &p_nodes)) || (rc = alloc(fresh, n_nodes * sizeof(rtc::QNode), &p_qnodes)) || (rc = alloc(fresh, 12 * (size_t)n * sizeof(double), &p_g64)) ||
+    if ((rc = alloc(fresh, n_nodes * sizeof(rtc::BvhNode), &p_nodes)) || (rc = alloc(fresh, 12 * (size_t)n * sizeof(double), &p_g64)) ||
         (rc = alloc(fresh, 12 * (size_t)n * sizeof(float), &p_g32)) || (rc = alloc(fresh, (size_t)n * sizeof(int32_t), &p_leaf)) ||
         (rc = alloc(fresh, (size_t)n * sizeof(int32_t), &p_row)) || (rc = alloc(fresh, n_nodes * sizeof(uint32_t), &p_arr2)) ||
         (rc = alloc(temp, 6 * (size_t)n * sizeof(float), &p_boxes)) || (rc = alloc(temp, 6 * sizeof(uint32_t), &p_bounds)) ||
@@ -900,18 +663,7 @@ int rebuild_triangle_bvh_device(rtc_scene* sc) {
     TRY_B(hipMemcpy(p_bounds, bounds_init, sizeof(bounds_init), hipMemcpyHostToDevice));
     const dim3 blk(256);
     auto grid_for = [](long long items) { return dim3((unsigned)((items + 255) / 256)); };
-    for (int pass = 0; pass < 2; pass++) {
-        // item boxes; if the triangles have moved to coordinates the padding was not made for, once more with a larger one
-        hipLaunchKernelGGL(rtc::lbvh_boxes_kernel, grid_for(n), blk, 0, nullptr, n, sc->d_titems, sc->d64.tri_geom, (float*)p_boxes, (uint32_t*)p_bounds, sc->pad_abs);
-        uint32_t b[6];
-        TRY_B(hipMemcpy(b, p_bounds, sizeof(b), hipMemcpyDeviceToHost));
-        double max_abs = 0;
-        for (int a = 0; a < 6; a++) { uint32_t o = b[a]; uint32_t u = (o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o; float f; memcpy(&f, &u, 4); max_abs = std::max(max_abs, (double)std::fabs(f)); }
-        if (!std::isfinite(max_abs)) return bail(fail(RTC_ERR_INVALID, "triangle rows are not finite"));
-        if (RTC_PAD_OF_EXTENT * max_abs <= sc->pad_abs) break;
-        sc->pad_abs = 2 * RTC_PAD_OF_EXTENT * max_abs;
-        TRY_B(hipMemcpy(p_bounds, bounds_init, sizeof(bounds_init), hipMemcpyHostToDevice));
-    }
+    hipLaunchKernelGGL(rtc::lbvh_boxes_kernel, grid_for(n), blk, 0, nullptr, n, sc->d_titems, sc->d64.tri_geom, (float*)p_boxes, (uint32_t*)p_bounds);
     int32_t deepest = 0;
     // finest Morton grid first (21 bits per axis); a coarser one if that tree is too deep for the traversal stack
     const int drop_bits[3] = {0, 18, 33};
@@ -949,18 +701,11 @@ int rebuild_triangle_bvh_device(rtc_scene* sc) {
 #undef TRY_B
     if (n_leaves == 1) deepest = 1;
     if (deepest > RTC_BVH_STACK - 1) { bail(0); return fail(RTC_ERR_LIMIT, "GPU-built triangle BVH is %d levels deep, the traversal stack holds %d", deepest, RTC_BVH_STACK - 1); }
-    {
-        const rtc::TreeGrid old = sc->d64.tgrid;
-        double max_abs = 0;
-        if ((rc = quantize_triangle_tree(sc, (const rtc::BvhNode*)p_nodes, (int)n_nodes, (rtc::QNode*)p_qnodes, &max_abs)) ||
-            hipDeviceSynchronize() != hipSuccess) { sc->d64.tgrid = sc->d32.tgrid = old; return bail(rc ? rc : fail(RTC_ERR_HIP, "quantising the rebuilt tree failed")); }
-    }
     temp.release();
     sc->tbvh_mem.release();
     sc->tbvh_mem = fresh;
     fresh.ptrs.clear();
-    sc->d64.tnodes = sc->d32.tnodes = (const rtc::QNode*)p_qnodes;
-    sc->d_tbuild = (rtc::BvhNode*)p_nodes;
+    sc->d64.tnodes = sc->d32.tnodes = (const rtc::BvhNode*)p_nodes;
     sc->d64.n_tnodes = sc->d32.n_tnodes = (int32_t)n_nodes;
     sc->d64.tb_geom = (const double*)p_g64; sc->d32.tb_geom = (const float*)p_g32;
     sc->d64.tb_leaf = sc->d32.tb_leaf = (const int32_t*)p_leaf;
@@ -977,20 +722,13 @@ int refit_triangle_bvh_device(rtc_scene* sc) {
     const int n = sc->n_titems, n_nodes = sc->d64.n_tnodes;
     if (n == 0 || n_nodes == 0) return 0;
     if (!sc->d_tb_row || !sc->d_tparent || !sc->d_tarrived) return fail(RTC_ERR_HIP, "internal: refit tables missing");
-    if (!sc->d_tbuild) return fail(RTC_ERR_HIP, "internal: refit tables missing");
     const dim3 blk(256);
+    HIP_TRY(hipMemset(sc->d_tarrived, 0, (size_t)n_nodes * sizeof(uint32_t)));
     hipLaunchKernelGGL(rtc::bvh_gather_rows_kernel, dim3((unsigned)((12LL * n + 255) / 256)), blk, 0, nullptr, n, (const int32_t*)sc->d_tb_row,
                        sc->d64.tri_geom, sc->d32.tri_geom, const_cast<double*>(sc->d64.tb_geom), const_cast<float*>(sc->d32.tb_geom));
-    for (int pass = 0; pass < 2; pass++) {
-        HIP_TRY(hipMemset(sc->d_tarrived, 0, (size_t)n_nodes * sizeof(uint32_t)));
-        hipLaunchKernelGGL(rtc::bvh_refit_kernel, dim3((unsigned)((n_nodes + 255) / 256)), blk, 0, nullptr, n_nodes, sc->d_tbuild,
-                           (const int32_t*)sc->d_tparent, sc->d64.tb_geom, sc->d_tarrived, sc->pad_abs);
-        HIP_TRY(hipGetLastError());
-        double max_abs = 0;
-        if (int rc = quantize_triangle_tree(sc, sc->d_tbuild, n_nodes, const_cast<rtc::QNode*>(sc->d64.tnodes), &max_abs)) return rc;
-        if (RTC_PAD_OF_EXTENT * max_abs <= sc->pad_abs) break;
-        sc->pad_abs = 2 * RTC_PAD_OF_EXTENT * max_abs;      // moved to coordinates the padding was not made for: once more
-    }
+    hipLaunchKernelGGL(rtc::bvh_refit_kernel, dim3((unsigned)((n_nodes + 255) / 256)), blk, 0, nullptr, n_nodes, const_cast<rtc::BvhNode*>(sc->d64.tnodes),
+                       (const int32_t*)sc->d_tparent, sc->d64.tb_geom, sc->d_tarrived);
+    HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
     for (Workspace* w : sc->workspaces) w->fb_age = std::min(w->fb_age, 1);
     return 0;
@@ -1027,69 +765,8 @@ struct WorkspaceLease {
     }
 };
 
-// ---- hit pool ----
-inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
-template <class R> size_t pool_record_bytes(int n_lights) { return rtc::REC_FIELDS * sizeof(R) + (size_t)n_lights * (3 * sizeof(R) + 4) + 4 + 8; }
-// carves [n_slots pixel slots + pool_cap secondary records] out of `base`; returns the bytes needed (base may be NULL)
-template <class R> size_t carve_pool(void* base, int n_slots, int pool_cap, int n_lights, rtc::HitPool<R>& P) {
-    const size_t cap = (size_t)n_slots + (size_t)pool_cap;
-    char* p = static_cast<char*>(base);
-    size_t off = 0;
-    auto take = [&](size_t bytes) { char* q = p ? p + off : nullptr; off = align_up(off + bytes, 256); return q; };
-    P.rec = reinterpret_cast<R*>(take(rtc::REC_FIELDS * cap * sizeof(R)));
-    P.mean = reinterpret_cast<R*>(take((size_t)n_lights * 3 * cap * sizeof(R)));
-    P.lit = reinterpret_cast<int32_t*>(take((size_t)n_lights * cap * 4));
-    P.next = reinterpret_cast<int32_t*>(take(cap * 4));
-    P.tag = reinterpret_cast<uint32_t*>(take(2 * cap * 4));
-    P.state = reinterpret_cast<int32_t*>(take((size_t)n_slots * 4));
-    P.cap = (int32_t)cap; P.n_slots = n_slots; P.sub_cap = pool_cap / RTC_POOL_SHARDS; P.n_lights = n_lights;
-    return off;
-}
-
-#define RTC_MAX_PASS_ENTRIES 65536        /* waves per pass: 4 M pixel slots */
-#define RTC_POOL_BUDGET (3ULL << 30)      /* the hit pool of one workspace never exceeds this: larger frames are traced in passes */
-
-// records the secondary pool gets for a pass of n_slots pixel slots (development / test override: RTC_POOL_CAP)
-long long secondary_pool_cap(const rtc_scene* sc, int depth, long long n_slots) {
-    if (!sc->has_secondary || depth == 0) return 0;
-    long long cap = (sc->branching ? 2 : 1) * n_slots + 65536;
-    if (const char* e = getenv("RTC_POOL_CAP")) { long long v = atoll(e); if (v >= 0 && v < cap) cap = v; }
-    return cap / (64 * RTC_POOL_SHARDS) * (64 * RTC_POOL_SHARDS);
-}
-
-int g_shadow_cells = [] { const char* e = getenv("RTC_SHADOW_CELLS"); int v = e ? atoi(e) : 16; return v >= 1 ? v : 16; }();
-
-// One pass of the three kernels (+ redo) over launch entries [entry0, entry0 + 4 * blocks) with the pool in `mem`.
-template <class R, bool PROF, bool CSG>
-void launch_pass(const rtc::DScene<R>& S, const rtc_scene* sc, const rtc_camera* cam, rtc::DFrame F, void* mem, int n_slots, int pool_cap,
-                 rtc::PoolCtrl* ctrl, rtc::PoolCtrl* ctrl_next, double eps, double eps_rel, hipStream_t stream) {
-    if (getenv("RTC_FUSED")) {
-        hipLaunchKernelGGL((fused_kernel<R, PROF, CSG>), dim3((unsigned)(n_slots / RTC_BLOCK)), dim3(RTC_BLOCK), 0, stream, S, make_camera<R>(*cam), F, (R)eps, (R)eps_rel);
-        return;
-    }
-    rtc::HitPool<R> P;
-    carve_pool<R>(mem, n_slots, pool_cap, S.n_lights, P);
-    P.ctrl = ctrl; P.ctrl_next = ctrl_next; P.cells_per_group = g_shadow_cells;
-    const dim3 block(RTC_BLOCK), grid((unsigned)(n_slots / RTC_BLOCK));
-    hipLaunchKernelGGL((trace_kernel<R, PROF, CSG>), grid, block, 0, stream, S, make_camera<R>(*cam), F, P, (R)eps, (R)eps_rel);
-    if (S.n_lights > 0) {
-        long long combos = 0;
-        for (int l = 0; l < sc->n_lights; l++) combos += (sc->light_samples[l] + g_shadow_cells - 1) / g_shadow_cells;
-        if (combos > 65535) combos = 65535;                       // (validate() refuses scenes beyond it)
-        const int rows = (P.cap + 63) / 64;                       // per (light, cell group)
-        const int per_block = RTC_SHADOW_ROWS * (RTC_BLOCK / 64);
-        hipLaunchKernelGGL((shadow_kernel<R, PROF, CSG>), dim3((unsigned)((rows + per_block - 1) / per_block), (unsigned)combos), block, 0, stream, S, F, P, rows);
-    }
-    hipLaunchKernelGGL((resolve_kernel<R>), grid, block, 0, stream, S, (int)cam->hsize, (int)cam->vsize, F, P);
-    if (pool_cap > 0 || getenv("RTC_POOL_CAP")) {
-        const long long fill = (long long)sc->n_cus * RTC_REDO_WAVES(R, CSG);
-        hipLaunchKernelGGL((redo_kernel<R, PROF, CSG>), dim3((unsigned)std::max(1LL, std::min((long long)grid.x, fill))), block, 0, stream, S,
-                           make_camera<R>(*cam), F, P, (R)eps, (R)eps_rel);
-    }
-}
-
 int launch(rtc_scene* scene, const rtc_camera* cam, const rtc_render_opts* opts, int32_t n_tiles, const int32_t* tile_ids_dev,
-           double* rgb_dev, int32_t* hit_id_dev, int64_t* rays_dev, int64_t* work_dev, hipStream_t stream, int64_t* redone_dev = nullptr) {
+           double* rgb_dev, int32_t* hit_id_dev, int64_t* rays_dev, int64_t* work_dev, hipStream_t stream) {
     int T, precision, depth;
     double eps, eps_rel;
     if (int rc = check_render_args(scene, cam, opts, &T, &precision, &depth, &eps, &eps_rel)) return rc;
@@ -1103,30 +780,32 @@ int launch(rtc_scene* scene, const rtc_camera* cam, const rtc_render_opts* opts,
     F.n_tiles = n_tiles; F.tile_size = T; F.tiles_x = tiles_x; F.tile_ids = tile_ids_dev;
     F.rgb = rgb_dev; F.hit_id = hit_id_dev; F.rays = reinterpret_cast<unsigned long long*>(rays_dev);
     F.max_depth = depth; F.seed = opts ? opts->seed : 0;
-    F.redone = reinterpret_cast<unsigned long long*>(redone_dev);
     long long work = (long long)n_tiles * T * T;
     long long blocks = (work + RTC_BLOCK - 1) / RTC_BLOCK;
     if (blocks > 0x7FFFFFFFLL) return fail(RTC_ERR_LIMIT, "too many blocks");
     F.work = reinterpret_cast<unsigned long long*>(work_dev);
-    F.order = nullptr; F.cost = nullptr; F.entry0 = 0;
+    F.order = nullptr; F.cost = nullptr;
     const long long n_units = blocks * (RTC_BLOCK / 64);
     if (n_units > 0x7FFFFFFFLL) return fail(RTC_ERR_LIMIT, "too many blocks");
     F.n_units = (int32_t)n_units;
+    dim3 block(RTC_BLOCK);
     const bool csg = scene->has_csg;
     const bool feedback = !(opts && (opts->flags & RTC_FLAG_NO_FEEDBACK));
-    const int waves_per_simd = csg ? 2 : (precision == 64 ? RTC_TRACE_WAVES_F64 : RTC_TRACE_WAVES_F32);
+    const int waves_per_simd = csg ? 2 : (precision == 64 ? RTC_WAVES_F64 : RTC_WAVES_F32);
+    dim3 grid((unsigned)blocks);
     // spare launch-order entries for the quadrants of split units (3 more per split unit)
     const long long n_entries = ((n_units + 3 * (n_units / 4 + 64)) + RTC_BLOCK / 64 - 1) / (RTC_BLOCK / 64) * (RTC_BLOCK / 64);
     F.n_entries = (int32_t)n_units;
-    FbKey key;
-    memset(&key, 0, sizeof(key));
-    key.cam = *cam; key.precision = precision; key.depth = depth; key.tile_size = T; key.n_tiles = n_tiles; key.tile_ids = tile_ids_dev;
-    Workspace* ws = acquire_workspace(scene, stream, key);
-    if (!ws) return fail(RTC_ERR_NOMEM, "no workspace for this call");
-    WorkspaceLease lease = {scene, ws, stream};
     bool resort = false;
-    long long launch_entries = n_units;
+    Workspace* ws = nullptr;
+    WorkspaceLease lease = {scene, nullptr, stream};
     if (feedback) {
+        FbKey key;
+        memset(&key, 0, sizeof(key));
+        key.cam = *cam; key.precision = precision; key.depth = depth; key.tile_size = T; key.n_tiles = n_tiles; key.tile_ids = tile_ids_dev;
+        ws = acquire_workspace(scene, stream, key);
+        if (!ws) return fail(RTC_ERR_NOMEM, "no workspace for this call");
+        lease.ws = ws;
         if (ws->fb_units != n_units) {
             if (ws->used) HIP_TRY(hipStreamSynchronize(stream));        // frames that still read the old buffers
             ws->fb_mem.release(); ws->fb_mem.bytes = 0; ws->fb_units = 0; ws->fb_valid = false;
@@ -1157,55 +836,23 @@ int launch(rtc_scene* scene, const rtc_camera* cam, const rtc_render_opts* opts,
             (void)hipGetLastError();       // a not-ready query is not an error
             used = (used + RTC_BLOCK / 64 - 1) / (RTC_BLOCK / 64) * (RTC_BLOCK / 64);
             F.n_entries = (int32_t)used;
-            launch_entries = used;
+            grid = dim3((unsigned)(used / (RTC_BLOCK / 64)));
         }
     }
-    // ---- the hit pool: pixel slots of a pass + its secondary records; frames beyond the budget go in several passes ----
-    const int n_lights = scene->n_lights;
-    const size_t rec_bytes = precision == 64 ? pool_record_bytes<double>(n_lights) : pool_record_bytes<float>(n_lights);
-    long long pass_entries = std::min<long long>(launch_entries, RTC_MAX_PASS_ENTRIES);
-    while (pass_entries > RTC_BLOCK / 64 &&
-           (size_t)(pass_entries * 64 + secondary_pool_cap(scene, depth, pass_entries * 64)) * rec_bytes > RTC_POOL_BUDGET)
-        pass_entries = (pass_entries / 2 + RTC_BLOCK / 64 - 1) / (RTC_BLOCK / 64) * (RTC_BLOCK / 64);
-    {
-        const int n_slots = (int)(pass_entries * 64);
-        const int pool_cap = (int)secondary_pool_cap(scene, depth, n_slots);
-        rtc::HitPool<double> p64; rtc::HitPool<float> p32;
-        const size_t need = (precision == 64 ? carve_pool<double>(nullptr, n_slots, pool_cap, n_lights, p64) : carve_pool<float>(nullptr, n_slots, pool_cap, n_lights, p32));
-        if (ws->pool_bytes < need) {
-            if (ws->used) HIP_TRY(hipStreamSynchronize(stream));
-            if (ws->pool) { (void)hipFree(ws->pool); ws->pool = nullptr; ws->pool_bytes = 0; }
-            HIP_TRY(hipMalloc(&ws->pool, need));
-            ws->pool_bytes = need;
-        }
-        if (!ws->ctrl) {
-            HIP_TRY(hipMalloc((void**)&ws->ctrl, 2 * sizeof(rtc::PoolCtrl)));
-            HIP_TRY(hipMemsetAsync(ws->ctrl, 0, 2 * sizeof(rtc::PoolCtrl), stream));
-            ws->ctrl_cur = 0;
-        }
+#define RTC_LAUNCH_TRACE(R, PROF, CSG, SC, EPS, EPSREL) \
+    hipLaunchKernelGGL((trace_kernel<R, PROF, CSG>), grid, block, 0, stream, SC, make_camera<R>(*cam), F, (R)(EPS), (R)(EPSREL))
+    if (precision == 64) {
+        if (work_dev) { if (csg) RTC_LAUNCH_TRACE(double, true, true, scene->d64, eps, eps_rel); else RTC_LAUNCH_TRACE(double, true, false, scene->d64, eps, eps_rel); }
+        else { if (csg) RTC_LAUNCH_TRACE(double, false, true, scene->d64, eps, eps_rel); else RTC_LAUNCH_TRACE(double, false, false, scene->d64, eps, eps_rel); }
+    } else {
+        if (work_dev) { if (csg) RTC_LAUNCH_TRACE(float, true, true, scene->d32, eps, eps_rel); else RTC_LAUNCH_TRACE(float, true, false, scene->d32, eps, eps_rel); }
+        else { if (csg) RTC_LAUNCH_TRACE(float, false, true, scene->d32, eps, eps_rel); else RTC_LAUNCH_TRACE(float, false, false, scene->d32, eps, eps_rel); }
     }
-    for (long long e0 = 0; e0 < launch_entries; e0 += pass_entries) {
-        const long long e1 = std::min(launch_entries, e0 + pass_entries);
-        const int n_slots = (int)((e1 - e0) * 64);
-        const int pool_cap = (int)secondary_pool_cap(scene, depth, n_slots);
-        F.entry0 = e0;
-        rtc::PoolCtrl* ctrl = ws->ctrl + ws->ctrl_cur;
-        rtc::PoolCtrl* ctrl_next = ws->ctrl + (1 - ws->ctrl_cur);
-        ws->ctrl_cur = 1 - ws->ctrl_cur;
-#define RTC_LAUNCH_PASS(R, PROF, CSG, SC) launch_pass<R, PROF, CSG>(SC, scene, cam, F, ws->pool, n_slots, pool_cap, ctrl, ctrl_next, eps, eps_rel, stream)
-        if (precision == 64) {
-            if (work_dev) { if (csg) RTC_LAUNCH_PASS(double, true, true, scene->d64); else RTC_LAUNCH_PASS(double, true, false, scene->d64); }
-            else { if (csg) RTC_LAUNCH_PASS(double, false, true, scene->d64); else RTC_LAUNCH_PASS(double, false, false, scene->d64); }
-        } else {
-            if (work_dev) { if (csg) RTC_LAUNCH_PASS(float, true, true, scene->d32); else RTC_LAUNCH_PASS(float, true, false, scene->d32); }
-            else { if (csg) RTC_LAUNCH_PASS(float, false, true, scene->d32); else RTC_LAUNCH_PASS(float, false, false, scene->d32); }
-        }
-#undef RTC_LAUNCH_PASS
-        HIP_TRY(hipGetLastError());
-    }
+#undef RTC_LAUNCH_TRACE
+    HIP_TRY(hipGetLastError());
     if (feedback && resort) {
         // this frame's costs -> the order the next frame of this view launches in (other buffer: the
-        // kernels above may still be reading the current one)
+        // kernel above may still be reading the current one)
         hipLaunchKernelGGL(order_kernel, dim3(1), dim3(1024), 0, stream, ws->fb_cost, ws->fb_order[1 - ws->fb_cur], (int)n_units,
                            (int)n_entries, scene->n_cus * 4 * waves_per_simd, g_split4, g_split16, ws->fb_used_dev);
         ws->fb_used_known = false;
@@ -1247,7 +894,7 @@ int render_host(rtc_scene* scene, const rtc_camera* cam, const rtc_render_opts* 
     if (int rc = grow(scene->out_rgb, scene->out_rgb_px, n_px, 3 * sizeof(double))) return rc;
     if (hit_id_out) if (int rc = grow(scene->out_id, scene->out_id_px, n_px, sizeof(int32_t))) return rc;
     if (tiled) if (int rc = grow(scene->out_tiles, scene->out_tiles_n, (size_t)n_tiles, sizeof(int32_t))) return rc;
-    if (!scene->out_rays) HIP_TRY(hipMalloc((void**)&scene->out_rays, 14 * sizeof(int64_t)));
+    if (!scene->out_rays) HIP_TRY(hipMalloc((void**)&scene->out_rays, 13 * sizeof(int64_t)));
     if (!scene->out_e0) HIP_TRY(hipEventCreate(&scene->out_e0));
     if (!scene->out_e1) HIP_TRY(hipEventCreate(&scene->out_e1));
     double* d_rgb = scene->out_rgb; int32_t* d_id = hit_id_out ? scene->out_id : nullptr; int64_t* d_rays = scene->out_rays;
@@ -1258,23 +905,22 @@ int render_host(rtc_scene* scene, const rtc_camera* cam, const rtc_render_opts* 
     if (tiled) TRY_C(hipMemsetAsync(d_rgb, 0, n_px * 3 * sizeof(double), nullptr));
     if (hit_id_out) TRY_C(hipMemsetAsync(d_id, 0xFF, n_px * sizeof(int32_t), nullptr));
     const bool want_work = stats_out && opts && (opts->flags & RTC_FLAG_COUNT_WORK);
-    TRY_C(hipMemsetAsync(d_rays, 0, 14 * sizeof(int64_t), nullptr));
+    TRY_C(hipMemsetAsync(d_rays, 0, 13 * sizeof(int64_t), nullptr));
     if (tiled) TRY_C(hipMemcpy(d_tiles, tile_ids, (size_t)n_tiles * sizeof(int32_t), hipMemcpyHostToDevice));
     TRY_C(hipEventRecord(e0, nullptr));
-    rc = launch(scene, cam, opts, n_tiles, d_tiles, d_rgb, d_id, d_rays, want_work ? d_rays + 4 : nullptr, nullptr, d_rays + 13);
+    rc = launch(scene, cam, opts, n_tiles, d_tiles, d_rgb, d_id, d_rays, want_work ? d_rays + 4 : nullptr, nullptr);
     if (rc) return rc;
     TRY_C(hipEventRecord(e1, nullptr));
     TRY_C(hipMemcpy(rgb_out, d_rgb, n_px * 3 * sizeof(double), hipMemcpyDeviceToHost));     // null stream: after the kernel
     if (hit_id_out) TRY_C(hipMemcpy(hit_id_out, d_id, n_px * sizeof(int32_t), hipMemcpyDeviceToHost));
     if (stats_out) {
-        int64_t host_rays[14];
+        int64_t host_rays[13];
         TRY_C(hipMemcpy(host_rays, d_rays, sizeof(host_rays), hipMemcpyDeviceToHost));
         float ms = 0;
         TRY_C(hipEventElapsedTime(&ms, e0, e1));
         memcpy(stats_out->rays, host_rays, 4 * sizeof(int64_t));
         if (want_work) memcpy(stats_out->work, host_rays + 4, 8 * sizeof(int64_t));
         stats_out->shadow_rays_culled = host_rays[12];
-        stats_out->pixels_redone = host_rays[13];
         stats_out->kernel_ms = ms;
     }
 #undef TRY_C
@@ -1489,15 +1135,15 @@ int rtc_render_ppm(rtc_scene* scene, const rtc_camera* cam, const rtc_render_opt
         HIP_TRY(hipMalloc((void**)&scene->out_ppm, total + 2 * sizeof(double)));
         scene->out_ppm_bytes = total + sizeof(double);
     }
-    if (!scene->out_rays) HIP_TRY(hipMalloc((void**)&scene->out_rays, 14 * sizeof(int64_t)));
+    if (!scene->out_rays) HIP_TRY(hipMalloc((void**)&scene->out_rays, 13 * sizeof(int64_t)));
     double* d_rgb = scene->out_rgb; int64_t* d_rays = scene->out_rays;
     double* d_max = reinterpret_cast<double*>(scene->out_ppm);             // 8 bytes in front of the file
     uint8_t* d_out = scene->out_ppm + sizeof(double);
     int rc = 0;
 #define TRY_C(expr) HIP_TRY(expr)
-    TRY_C(hipMemsetAsync(d_rays, 0, 14 * sizeof(int64_t), nullptr));
+    TRY_C(hipMemsetAsync(d_rays, 0, 13 * sizeof(int64_t), nullptr));
     const bool want_work = stats_out && opts && (opts->flags & RTC_FLAG_COUNT_WORK);
-    rc = launch(scene, cam, opts, 0, nullptr, d_rgb, nullptr, d_rays, want_work ? d_rays + 4 : nullptr, nullptr, d_rays + 13);
+    rc = launch(scene, cam, opts, 0, nullptr, d_rgb, nullptr, d_rays, want_work ? d_rays + 4 : nullptr, nullptr);
     if (rc) return rc;
     TRY_C(hipMemcpy(d_out, header, (size_t)hlen, hipMemcpyHostToDevice));
     const uint8_t newline = 10;
@@ -1514,7 +1160,6 @@ int rtc_render_ppm(rtc_scene* scene, const rtc_camera* cam, const rtc_render_opt
         TRY_C(hipMemcpy(stats_out->rays, d_rays, 4 * sizeof(int64_t), hipMemcpyDeviceToHost));
         if (want_work) TRY_C(hipMemcpy(stats_out->work, d_rays + 4, 8 * sizeof(int64_t), hipMemcpyDeviceToHost));
         TRY_C(hipMemcpy(&stats_out->shadow_rays_culled, d_rays + 12, sizeof(int64_t), hipMemcpyDeviceToHost));
-        TRY_C(hipMemcpy(&stats_out->pixels_redone, d_rays + 13, sizeof(int64_t), hipMemcpyDeviceToHost));
     }
 #undef TRY_C
     return 0;

@@ -15,7 +15,6 @@
 #include <stdint.h>
 
 #include "../../include/rtc_api.h"
-#include "rtc_qnode.hpp"
 
 #ifndef RTC_BLOCK
 #define RTC_BLOCK 256
@@ -108,7 +107,6 @@ template <class R> __device__ __forceinline__ V3<R> xtvector(const R* __restrict
 // ------------------------------------------------------------------------------------------
 // device scene (struct of device pointers; one instance per precision)
 // ------------------------------------------------------------------------------------------
-// the builders' working form of a node (fp32 boxes); the kernels walk QNodes made from these
 struct alignas(64) BvhNode { float box[12]; int32_t child[2]; int32_t pad[2]; };
 
 template <class R> struct DScene {
@@ -118,15 +116,14 @@ template <class R> struct DScene {
     const R* xform;
     const R* tri_geom; const R* tri_norm; const int32_t* tri_leaf;
     int32_t n_bvh_nodes;           // 0 = no bounded items
-    // one 32-byte record per node (rtc_qnode.hpp): both children's boxes quantised outward on the node's own
-    // frame, in BOTH precisions, and the two child references
+    // one 64-byte record per node = one cache line per visit: boxes of both children in fp32 (in
+    // BOTH precisions; padded outward, see pad_boxes) and the two child references
     // (>= 0 inner node; < 0: ~c = first<<4 | (count-1); RTC_EMPTY_CHILD = none)
-    const QNode* nodes;
-    TreeGrid ogrid, tgrid;         // grid and whole-tree box of the object BVH and of the triangle BVH
+    const BvhNode* nodes;
     const int32_t* bvh_prims;      // prim codes in BVH leaf order (analytic leaves and CSG roots only)
     // triangles have a BVH of their own whose leaves index tb_* directly (no prim-code indirection):
     int32_t n_tnodes;
-    const QNode* tnodes;
+    const BvhNode* tnodes;
     const R* tb_geom;              // [n_tris][12] tri_geom rows in BVH leaf order
     const int32_t* tb_leaf;        // [n_tris] leaf id, bit 31 set = does not cast shadows
     int32_t n_unbounded; const int32_t* unbounded_prims;
@@ -153,7 +150,6 @@ struct DFrame {
     int32_t tile_size, tiles_x;
     const int32_t* tile_ids;     // NULL: tile k = k, output in [x][y][c]; else compact tile layout
     double* rgb; int32_t* hit_id; unsigned long long* rays; unsigned long long* work;
-    unsigned long long* redone;  // pixels traced by redo_kernel are counted here (may be NULL)
     int32_t max_depth;
     uint64_t seed;
     // Launch order of the pixel kernels: unit = 64 work items = one 8x8 pixel block.  The k-th wave of the
@@ -161,13 +157,13 @@ struct DFrame {
     // entries start first): part 0 = the whole block, 1..4 = one 4x4 quadrant of it, 5..20 = one 2x2 piece
     // (the dearest blocks are spread over 4 or 16 waves when the GPU has slots to spare), -1 = nothing.
     int32_t n_units, n_entries;
-    long long entry0;            // first entry of this pass (a frame with more entries than the hit pool has slots is traced in passes)
     const int32_t* order;        // [n_entries], or NULL = units 0, 1, 2, ... whole
     uint32_t* cost;              // [n_units] wall-clock ticks spent on the unit (parts add up; zeroed by the host), or NULL
 };
 
-// the unit of launch entry `entry` (-1 if there is none) and whether lane `lane` of its wave takes part
-__device__ __forceinline__ long long entry_unit(const DFrame& F, long long entry, int lane, bool& lane_on) {
+// the unit of this wave (-1 if there is none) and which of its lanes take part
+__device__ __forceinline__ long long wave_unit(const DFrame& F, bool& lane_on) {
+    long long entry = (long long)blockIdx.x * (RTC_BLOCK / 64) + (threadIdx.x >> 6);
     lane_on = true;
     if (!F.order) return entry < F.n_units ? entry : -1;
     if (entry >= F.n_entries) return -1;
@@ -175,13 +171,11 @@ __device__ __forceinline__ long long entry_unit(const DFrame& F, long long entry
     if (e < 0) return -1;
     int u = e >> 5, part = e & 31;
     if (u >= F.n_units || part > 20) return -1;
-    const int lx = lane & 7, ly = (lane >> 3) & 7;
+    const int lx = threadIdx.x & 7, ly = (threadIdx.x >> 3) & 7;
     if (part >= 5) lane_on = (lx >> 1) == ((part - 5) & 3) && (ly >> 1) == ((part - 5) >> 2);
     else if (part != 0) lane_on = (((ly >> 2) << 1) | (lx >> 2)) == part - 1;
     return u;
 }
-// the entry of this wave of a pixel kernel: one wave per entry, entries of the pass from F.entry0
-__device__ __forceinline__ long long wave_entry(const DFrame& F) { return F.entry0 + (long long)blockIdx.x * (RTC_BLOCK / 64) + (threadIdx.x >> 6); }
 
 // c: rays traced (primary, shadow, reflection, refraction).  w (PROF builds only): BVH node
 // visits (2 box tests each), triangle tests, analytic leaf tests, CSG root evaluations, shaded
@@ -384,84 +378,49 @@ struct PrimCode {
         : kind((int)((uint32_t)c >> 28)), idx((int)((uint32_t)c & 0x07FFFFFFu)), noshadow((((uint32_t)c >> 27) & 1u) != 0) {}
 };
 
-// The part of the ray inside a tree's box, in R: [t0, t1] clipped to (tlo, limit).  false = the ray misses the tree.
-// The fp32 box tests below then run on the ray re-based at t0, so that their rounding is relative to the tree's
-// size, not to how far away the ray started (a camera thousands of units from a small mesh).
-template <class R> __device__ __forceinline__ bool clip_to_tree(const TreeGrid& G, const Ray<R>& ray, R tlo, R limit, R& t0, R& t1) {
-    t0 = tlo; t1 = limit;
-    const R o[3] = {ray.o.x, ray.o.y, ray.o.z}, d[3] = {ray.d.x, ray.d.y, ray.d.z};
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-        const R lo = R(G.root[k]), hi = R(G.root[3 + k]);
-        if (d[k] == R(0)) { if (o[k] < lo || o[k] > hi) return false; }
-        else {
-            const R inv = R(1) / d[k];
-            R a = (lo - o[k]) * inv, b = (hi - o[k]) * inv;
-            if (a > b) { R t = a; a = b; b = t; }
-            a -= abs_(a) * R(1e-6); b += abs_(b) * R(1e-6);
-            t0 = max_(t0, a); t1 = min_(t1, b);
-        }
-    }
-    return t0 <= t1;
-}
-
 // Visitor V: bool prim(code) -> true = stop the traversal; R limit() = current far bound.
 // Boxes are visited when their slab interval overlaps (tlo, limit()).
 // TRIS = false: the object BVH (leaves hold prim codes -> vis.prim); TRIS = true: the triangle
 // BVH (leaves are ranges of tb_* rows -> vis.tri).  Returns true if the visitor stopped it.
 template <class R, class V, bool TRIS>
 __device__ __forceinline__ bool traverse_bvh(const DScene<R>& S, const Ray<R>& ray, R tlo, V& vis, int* stack /* LDS, stride RTC_BLOCK */) {
-    const QNode* __restrict__ nodes = TRIS ? S.tnodes : S.nodes;
-    const TreeGrid& G = TRIS ? S.tgrid : S.ogrid;
-    R t_in, t_out;
-    if (!clip_to_tree(G, ray, tlo, vis.limit(), t_in, t_out)) return false;
-    // Box tests run in fp32 whatever R is, on the ray re-based at `base` (where it enters the tree).  The boxes are
-    // padded outward on the host (pad_boxes: 2e-5 relative, >= 2e-5 absolute, >= 4e-7 of the scene's extent -- which
-    // covers rounding the re-based ray and the frame arithmetic to fp32) and quantised outward, and the slab
-    // distances get a 1e-5 relative slack before every comparison: the test can only accept MORE than an exact one
-    // would, never less, so no leaf the leaf test would accept is culled.
-    // A direction component of 0 gets a huge finite reciprocal instead of inf, so that no 0 * inf appears (the sign
-    // of plane - origin then decides, as it should, and the padding covers an origin that sits on the slab plane).
-    const R base = (t_in > -inf_<R>() && t_in < inf_<R>()) ? t_in : R(0);
-    const float rox = (float)(ray.o.x + ray.d.x * base), roy = (float)(ray.o.y + ray.d.y * base), roz = (float)(ray.o.z + ray.d.z * base);
+    const BvhNode* __restrict__ nodes = TRIS ? S.tnodes : S.nodes;
+    // Box tests run in fp32 whatever R is: the boxes are padded outward by 2e-5 (relative, >= 2e-5
+    // absolute) on the host, which covers rounding the ray to fp32, and the slab distances get a
+    // 1e-5 relative slack before every comparison -- the test can only accept MORE than an exact
+    // one would, never less, so no leaf the leaf test would accept is culled.
+    // slab distance (b - o) / d as one fused multiply-add b * (1/d) + (-o/d); a direction component of 0
+    // gets a huge finite reciprocal instead of inf, so that no 0 * inf appears (the sign of b - o then
+    // decides, as it should, and the outward padding covers an origin that sits on the slab plane)
     float ix = 1.0f / (float)ray.d.x, iy = 1.0f / (float)ray.d.y, iz = 1.0f / (float)ray.d.z;
     if (!(fabsf(ix) <= 1e30f)) ix = copysignf(1e30f, (float)ray.d.x);
     if (!(fabsf(iy) <= 1e30f)) iy = copysignf(1e30f, (float)ray.d.y);
     if (!(fabsf(iz) <= 1e30f)) iz = copysignf(1e30f, (float)ray.d.z);
-    // node origin = grid.lo + g * grid.cell; relative to the ray start: (grid.lo - ro) + g * cell
-    const float gx0 = G.lo[0] - rox, gy0 = G.lo[1] - roy, gz0 = G.lo[2] - roz;
-    const float tlo32 = (float)(t_in - base) - 1e-30f;
+    const float ox = -(float)ray.o.x * ix, oy = -(float)ray.o.y * iy, oz = -(float)ray.o.z * iz;
+    const float tlo32 = (float)tlo;
     int sp = 0;
     int node = 0;
     while (true) {
         if (node >= 0) {
             vis.cnt.work(W_NODE);
-            const uint4* q = reinterpret_cast<const uint4*>(nodes + node);     // 2 x 16-byte loads
-            const uint4 qa = q[0], qb = q[1];
-            const uint32_t g_x = qa.x & RTC_QGRID_MAX, g_y = ((qa.x >> 21) | (qa.y << 11)) & RTC_QGRID_MAX, g_z = (qa.y >> 10) & RTC_QGRID_MAX;
-            // A = (origin - ray start) / d, B = scale / d: slab distance of plane q is q * B + A
-            const float ax = fmaf((float)g_x, G.cell[0], gx0) * ix, ay = fmaf((float)g_y, G.cell[1], gy0) * iy, az = fmaf((float)g_z, G.cell[2], gz0) * iz;
-            const float bx = __uint_as_float((qa.z & 255u) << 23) * ix, by = __uint_as_float(((qa.z >> 8) & 255u) << 23) * iy,
-                        bz = __uint_as_float(((qa.z >> 16) & 255u) << 23) * iz;
-            const int c0 = (int)qb.z, c1 = (int)qb.w;
-            // child0: lo = qa.w bytes 0..2, hi = qa.w byte 3, qb.x bytes 0..1; child1: lo = qb.x bytes 2..3, qb.y byte 0, hi = qb.y bytes 1..3
+            const float4* q = reinterpret_cast<const float4*>(nodes + node);     // 4 x 16-byte loads of one line
+            const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+            const float b[12] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w};
+            int c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y);
             float near[2], far[2];
-            {
-                const float x0 = fmaf((float)(qa.w & 255u), bx, ax), y0 = fmaf((float)((qa.w >> 8) & 255u), by, ay), z0 = fmaf((float)((qa.w >> 16) & 255u), bz, az);
-                const float x1 = fmaf((float)(qa.w >> 24), bx, ax), y1 = fmaf((float)(qb.x & 255u), by, ay), z1 = fmaf((float)((qb.x >> 8) & 255u), bz, az);
-                const float n = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
-                const float f = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
-                near[0] = n - fabsf(n) * 1e-5f; far[0] = f + fabsf(f) * 1e-5f;
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                const float* lo = b + 6 * k; const float* hi = lo + 3;
+                float x0 = fmaf(lo[0], ix, ox), x1 = fmaf(hi[0], ix, ox);
+                float y0 = fmaf(lo[1], iy, oy), y1 = fmaf(hi[1], iy, oy);
+                float z0 = fmaf(lo[2], iz, oz), z1 = fmaf(hi[2], iz, oz);
+                float n = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
+                float f = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
+                near[k] = n - fabsf(n) * 1e-5f;
+                far[k] = f + fabsf(f) * 1e-5f;
             }
-            {
-                const float x0 = fmaf((float)((qb.x >> 16) & 255u), bx, ax), y0 = fmaf((float)(qb.x >> 24), by, ay), z0 = fmaf((float)(qb.y & 255u), bz, az);
-                const float x1 = fmaf((float)((qb.y >> 8) & 255u), bx, ax), y1 = fmaf((float)((qb.y >> 16) & 255u), by, ay), z1 = fmaf((float)(qb.y >> 24), bz, az);
-                const float n = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
-                const float f = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
-                near[1] = n - fabsf(n) * 1e-5f; far[1] = f + fabsf(f) * 1e-5f;
-            }
-            float lim = (float)(vis.limit() - base);
-            lim += fabsf(lim) * 1e-6f + 1e-30f;
+            float lim = (float)vis.limit();
+            lim += fabsf(lim) * 1e-6f;
             bool h0 = c0 != RTC_EMPTY_CHILD && near[0] <= far[0] && far[0] >= tlo32 && near[0] <= lim;
             bool h1 = c1 != RTC_EMPTY_CHILD && near[1] <= far[1] && far[1] >= tlo32 && near[1] <= lim;
             if (h0 && h1) {
@@ -495,9 +454,22 @@ template <class R, class V> __device__ __forceinline__ void traverse_objects(con
         // (Measured on shadow_glamour_shot: -11 % fp64, -16 % fp32; a per-object box test in front of each leaf test
         // gives all of it back -- the shadow rays of that scene pass through the boxes anyway.  A single object keeps
         // its BVH: there the root's box test spares the background pixels their fp64 leaf test.)
-        if (V::kFlatRootBox) {   // one box around all of them: the tree's own (padded) box, tested in R
-            R t_in, t_out;
-            if (!clip_to_tree(S.ogrid, ray, tlo, vis.limit(), t_in, t_out)) return;
+        if (V::kFlatRootBox) {   // one box around all of them (the root's only child): same conservative fp32 slab test as traverse_bvh's
+            float ix = 1.0f / (float)ray.d.x, iy = 1.0f / (float)ray.d.y, iz = 1.0f / (float)ray.d.z;
+            if (!(fabsf(ix) <= 1e30f)) ix = copysignf(1e30f, (float)ray.d.x);
+            if (!(fabsf(iy) <= 1e30f)) iy = copysignf(1e30f, (float)ray.d.y);
+            if (!(fabsf(iz) <= 1e30f)) iz = copysignf(1e30f, (float)ray.d.z);
+            const float ox = -(float)ray.o.x * ix, oy = -(float)ray.o.y * iy, oz = -(float)ray.o.z * iz;
+            const float* pb = S.nodes[0].box;
+            float x0 = fmaf(pb[0], ix, ox), x1 = fmaf(pb[3], ix, ox);
+            float y0 = fmaf(pb[1], iy, oy), y1 = fmaf(pb[4], iy, oy);
+            float z0 = fmaf(pb[2], iz, oz), z1 = fmaf(pb[5], iz, oz);
+            float n = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
+            float f = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
+            n -= fabsf(n) * 1e-5f; f += fabsf(f) * 1e-5f;
+            float lim = (float)vis.limit();
+            lim += fabsf(lim) * 1e-6f;
+            if (!(n <= f && f >= (float)tlo && n <= lim)) return;
         }
         for (int i = 0; i < S.n_flat_prims; i++)
             if (vis.prim(S.bvh_prims[i])) return;

@@ -46,24 +46,6 @@ def frac_off_by_more_than_one(a, b):
     return float((d > 1).mean())
 
 
-import contextlib
-
-
-@contextlib.contextmanager
-def small_pool(records):
-    """Renders inside run with a hit pool of `records` secondary records (RTC_POOL_CAP, read per launch): pixels whose
-    ray trees do not fit are given up by trace_kernel and traced in one lane by redo_kernel."""
-    old = os.environ.get("RTC_POOL_CAP")
-    os.environ["RTC_POOL_CAP"] = str(int(records))
-    try:
-        yield
-    finally:
-        if old is None:
-            del os.environ["RTC_POOL_CAP"]
-        else:
-            os.environ["RTC_POOL_CAP"] = old
-
-
 @pytest.fixture(scope="session")
 def oracle_cls():
     from oracle.oracle import Oracle, build

@@ -7,7 +7,7 @@ import ctypes as C
 import numpy as np
 import pytest
 
-from conftest import frac_off_by_more_than_one, load_golden, load_pack, ppm_levels, small_pool
+from conftest import frac_off_by_more_than_one, load_golden, load_pack, ppm_levels
 from ray_tracer_challenge_amd import _ffi
 from ray_tracer_challenge_amd.canvas import quantize
 from ray_tracer_challenge_amd.compile import compile_scene
@@ -244,36 +244,6 @@ def test_nested_and_blended_patterns_and_nested_csg(oracle_cls):
     assert frac_off_by_more_than_one(got32, want) <= 0.02
 
 
-@pytest.mark.parametrize("name,size", [("cover", None), ("csg_test", (160, 160)), ("shadow_glamour_shot_nojitter", (120, 48)),
-                                       ("teapot", None), ("dragons", (480, 192))])
-def test_full_hit_pool_is_still_exact(name, size, scenes):
-    """The hit pool of the deferred kernels (rtc_deferred.hpp) is sized for ordinary frames; a pixel whose ray tree finds
-    it full is given up and traced in one lane, shadow rays in place, by redo_kernel.  With no secondary records at all
-    (every pixel with a reflection or refraction hit is redone), with a handful, and with the default pool: the same
-    image bit for bit in fp64, the same ids, the same ray counts kind by kind."""
-    cam, world, sc = scenes(name)
-    if size:
-        cam = cam.resized(*size)
-    s1 = {}
-    a, ia = sc.render(cam, precision="fp64", want_ids=True, stats=s1)
-    a32, ia32 = sc.render(cam, precision="fp32", want_ids=True)
-    for records in (0, 512, 4096):
-        with small_pool(records):
-            s2 = {}
-            b, ib = sc.render(cam, precision="fp64", want_ids=True, stats=s2)
-            b32, ib32 = sc.render(cam, precision="fp32", want_ids=True)
-        np.testing.assert_allclose(a, b, rtol=0, atol=1e-12)
-        np.testing.assert_array_equal(ia, ib)
-        assert s1["rays"] == s2["rays"] and s1["shadow_rays_culled"] == s2["shadow_rays_culled"]
-        if name in ("cover", "dragons", "csg_test") and records == 0:
-            assert s2["pixels_redone"] > 0
-        # fp32: the two forms are compiled separately, so fused multiply-adds may fall differently and a ray that
-        # grazes an edge may land on either side of it -- the same gate as fp32 against the reference
-        assert (np.abs(a32 - b32).max(axis=2) > 1e-4).mean() <= 0.001
-        assert (ia32 != ib32).mean() <= 0.001
-    assert s1["pixels_redone"] == 0
-
-
 @pytest.mark.parametrize("name,size", [("cover", None), ("dragons", (480, 192)), ("teapot", None)])
 def test_launch_order_feedback_changes_nothing(name, size, scenes):
     """Frames after the first launch the dearest 8x8 blocks first (costs recorded by the previous frame on the
@@ -309,10 +279,7 @@ def test_jittered_area_light(scenes):
     a, ids_a = sj.render(cam, precision="fp64", want_ids=True, seed=1)
     b, _ = sj.render(cam, precision="fp64", seed=1)
     c, _ = sj.render(cam, precision="fp64", seed=2)
-    with small_pool(0):
-        lv, _ = sj.render(cam, precision="fp64", seed=1)
     np.testing.assert_array_equal(a, b)
-    np.testing.assert_allclose(a, lv, rtol=0, atol=1e-9)
     np.testing.assert_array_equal(ids_a, ids_plain)
     assert np.abs(a - c).max() > 1e-3
     mean = np.mean([sj.render(cam, precision="fp64", seed=s)[0] for s in range(3, 19)], axis=0)
@@ -373,7 +340,7 @@ def _same_image(a, b, ia, ib):
 @pytest.mark.parametrize("name,size", [("teapot", None), ("dragons", (480, 192)), ("cover", None)])
 def test_triangle_bvh_built_on_the_gpu(name, size):
     """rtc_scene_build_bvh_device: same image as with the host-built tree, in both precisions, through the
-    kernels; scenes without triangles are left alone."""
+    kernel; scenes without triangles are left alone."""
     cam, world, _ = load_pack(name)
     if size:
         cam = cam.resized(*size)

@@ -11,12 +11,3 @@ def test_radix_tree_index_arithmetic(tmp_path):
     subprocess.run(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(ROOT, "tests", "cpp", "lbvh_check.cpp")], check=True)
     out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout
     assert out.startswith("OK")
-
-
-def test_quantised_node_encoder_is_conservative(tmp_path):
-    """csrc/rtc_qnode.hpp (the 32-byte node both BVHs are stored as) compiles for the host too: the boxes a node
-    decodes to contain the boxes it was made from, for tiny, huge, flat and far-away boxes and absent children."""
-    exe = str(tmp_path / "qnode_check")
-    subprocess.run(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(ROOT, "tests", "cpp", "qnode_check.cpp")], check=True)
-    out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout
-    assert out.startswith("OK")
