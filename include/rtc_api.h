@@ -234,9 +234,11 @@ int rtc_render_tiles(rtc_scene *scene, const rtc_camera *cam, const rtc_render_o
  * tile_ids_dev == NULL renders the whole frame into the [x][y][c] layout; otherwise the
 * compact tile layout above.  rays_dev (may be NULL) is ADDED to and must hold 13 int64: [0..3] ray
  * counts, [4..11] the work counters of rtc_stats (RTC_FLAG_COUNT_WORK only), [12] shadow rays culled.  Asynchronous on
- * `stream` (a hipStream_t, NULL = default stream).  Render calls on one scene handle must be
- * stream-ordered (same stream, or synchronised by the caller): the handle owns the launch-order
- * buffers of RTC_FLAG_NO_FEEDBACK's comment and the ray pool of RTC_FLAG_WAVEFRONT. */
+ * `stream` (a hipStream_t, NULL = default stream).  A scene handle is immutable while frames are rendered and
+ * may be rendered from several host threads at once, one stream per call: every call takes a workspace of its own
+ * (the launch-order buffers of RTC_FLAG_NO_FEEDBACK's comment) from the handle and gives it back when its stream
+ * has finished with it.  The calls that change a scene (rtc_scene_update_triangles*, rtc_scene_refit_triangles,
+ * rtc_scene_build_bvh_device) must not run while frames of it are in flight. */
 int rtc_render_device(rtc_scene *scene, const rtc_camera *cam, const rtc_render_opts *opts,
                       int32_t n_tiles, const int32_t *tile_ids_dev,
                       double *rgb_dev, int32_t *hit_id_dev, int64_t *rays_dev, void *stream);

@@ -765,6 +765,23 @@ struct WorkspaceLease {
     }
 };
 
+// the trace kernel variant for (precision, counting, CSG / perturbed patterns) on `grid` workgroups
+void launch_trace(const rtc_scene* scene, const rtc_camera* cam, const rtc::DFrame& F, dim3 grid, int precision, bool prof, double eps, double eps_rel,
+                  hipStream_t stream) {
+    const dim3 block(RTC_BLOCK);
+    const bool csg = scene->has_csg;
+#define RTC_LAUNCH_TRACE(R, PROF, CSG, SC) \
+    hipLaunchKernelGGL((trace_kernel<R, PROF, CSG>), grid, block, 0, stream, SC, make_camera<R>(*cam), F, (R)eps, (R)eps_rel)
+    if (precision == 64) {
+        if (prof) { if (csg) RTC_LAUNCH_TRACE(double, true, true, scene->d64); else RTC_LAUNCH_TRACE(double, true, false, scene->d64); }
+        else { if (csg) RTC_LAUNCH_TRACE(double, false, true, scene->d64); else RTC_LAUNCH_TRACE(double, false, false, scene->d64); }
+    } else {
+        if (prof) { if (csg) RTC_LAUNCH_TRACE(float, true, true, scene->d32); else RTC_LAUNCH_TRACE(float, true, false, scene->d32); }
+        else { if (csg) RTC_LAUNCH_TRACE(float, false, true, scene->d32); else RTC_LAUNCH_TRACE(float, false, false, scene->d32); }
+    }
+#undef RTC_LAUNCH_TRACE
+}
+
 int launch(rtc_scene* scene, const rtc_camera* cam, const rtc_render_opts* opts, int32_t n_tiles, const int32_t* tile_ids_dev,
            double* rgb_dev, int32_t* hit_id_dev, int64_t* rays_dev, int64_t* work_dev, hipStream_t stream) {
     int T, precision, depth;
@@ -788,7 +805,6 @@ int launch(rtc_scene* scene, const rtc_camera* cam, const rtc_render_opts* opts,
     const long long n_units = blocks * (RTC_BLOCK / 64);
     if (n_units > 0x7FFFFFFFLL) return fail(RTC_ERR_LIMIT, "too many blocks");
     F.n_units = (int32_t)n_units;
-    dim3 block(RTC_BLOCK);
     const bool csg = scene->has_csg;
     const bool feedback = !(opts && (opts->flags & RTC_FLAG_NO_FEEDBACK));
     const int waves_per_simd = csg ? 2 : (precision == 64 ? RTC_WAVES_F64 : RTC_WAVES_F32);
@@ -839,16 +855,7 @@ int launch(rtc_scene* scene, const rtc_camera* cam, const rtc_render_opts* opts,
             grid = dim3((unsigned)(used / (RTC_BLOCK / 64)));
         }
     }
-#define RTC_LAUNCH_TRACE(R, PROF, CSG, SC, EPS, EPSREL) \
-    hipLaunchKernelGGL((trace_kernel<R, PROF, CSG>), grid, block, 0, stream, SC, make_camera<R>(*cam), F, (R)(EPS), (R)(EPSREL))
-    if (precision == 64) {
-        if (work_dev) { if (csg) RTC_LAUNCH_TRACE(double, true, true, scene->d64, eps, eps_rel); else RTC_LAUNCH_TRACE(double, true, false, scene->d64, eps, eps_rel); }
-        else { if (csg) RTC_LAUNCH_TRACE(double, false, true, scene->d64, eps, eps_rel); else RTC_LAUNCH_TRACE(double, false, false, scene->d64, eps, eps_rel); }
-    } else {
-        if (work_dev) { if (csg) RTC_LAUNCH_TRACE(float, true, true, scene->d32, eps, eps_rel); else RTC_LAUNCH_TRACE(float, true, false, scene->d32, eps, eps_rel); }
-        else { if (csg) RTC_LAUNCH_TRACE(float, false, true, scene->d32, eps, eps_rel); else RTC_LAUNCH_TRACE(float, false, false, scene->d32, eps, eps_rel); }
-    }
-#undef RTC_LAUNCH_TRACE
+    launch_trace(scene, cam, F, grid, precision, work_dev != nullptr, eps, eps_rel, stream);
     HIP_TRY(hipGetLastError());
     if (feedback && resort) {
         // this frame's costs -> the order the next frame of this view launches in (other buffer: the

@@ -536,3 +536,43 @@ def test_ppm_quantisation_on_synthetic_frames():
             assert _ffi.lib().rtc_quantize_device(C.c_void_p(dev.data_ptr()), w, h, maxc, C.c_void_p(out.data_ptr()), C.c_void_p(stream)) == 0
             torch.cuda.synchronize()
             np.testing.assert_array_equal(out.cpu().numpy(), quantize(frame, clamp))
+
+
+def test_one_scene_handle_rendered_from_two_threads(scenes):
+    """a scene handle may be rendered from several host threads, one HIP stream per call.  Two threads render
+    two different views of one handle at the same time -- through rtc_render_device on streams of their own and through
+    rtc_render -- frame after frame (so that launch-order feedback is recorded, sorted and reused while the other thread
+    does the same for its view); every frame must equal the one a single thread gets."""
+    import threading
+    import torch
+    cam, world, sc = scenes("cover")
+    views = [cam.resized(160, 100), cam.resized(96, 128)]
+    want = [sc.render(v, precision="fp64", want_ids=True, feedback=False) for v in views]
+    dev = torch.device("cuda", 0)
+    errors = []
+
+    def worker(k):
+        try:
+            v = views[k]
+            stream = torch.cuda.Stream(device=dev)
+            frame = torch.zeros((v.hsize, v.vsize, 3), dtype=torch.float64, device=dev)
+            ids = torch.zeros((v.hsize, v.vsize), dtype=torch.int32, device=dev)
+            for it in range(12):
+                frame.fill_(-1.0)
+                torch.cuda.synchronize()
+                sc.render_device(v, frame.data_ptr(), ids_ptr=ids.data_ptr(), precision="fp64", stream=stream.cuda_stream)
+                stream.synchronize()
+                if not np.array_equal(frame.cpu().numpy(), want[k][0]) or not np.array_equal(ids.cpu().numpy(), want[k][1]):
+                    errors.append("device path, thread %d frame %d" % (k, it))
+                got, got_ids = sc.render(v, precision="fp64", want_ids=True)
+                if not np.array_equal(got, want[k][0]) or not np.array_equal(got_ids, want[k][1]):
+                    errors.append("host path, thread %d frame %d" % (k, it))
+        except Exception as e:          # noqa: BLE001 - reported below
+            errors.append("thread %d: %r" % (k, e))
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
