@@ -59,7 +59,7 @@ class SceneInfo(C.Structure):
 
 
 EXPORTS = ["rtc_version", "rtc_device_count", "rtc_last_error", "rtc_scene_create", "rtc_scene_destroy",
-           "rtc_scene_get_info", "rtc_render", "rtc_render_tiles", "rtc_render_device", "rtc_quantize_device",
+           "rtc_scene_get_info", "rtc_render", "rtc_render_tiles", "rtc_render_device", "rtc_render_device_noalloc", "rtc_quantize_device",
            "rtc_scatter_tiles_device", "rtc_frame_max_device", "rtc_ppm_body_device", "rtc_ppm_size", "rtc_render_ppm",
            "rtc_scene_build_bvh_device", "rtc_scene_update_triangles", "rtc_scene_refit_triangles", "rtc_scene_update_triangles_device",
            "rtc_host_alloc", "rtc_host_free"]
@@ -107,6 +107,7 @@ def lib():
         L.rtc_render_tiles.argtypes = [_P, C.POINTER(CameraDesc), C.POINTER(RenderOpts), C.c_int32, _P, _P, _P,
                                        C.POINTER(Stats)]
         L.rtc_render_device.argtypes = [_P, C.POINTER(CameraDesc), C.POINTER(RenderOpts), C.c_int32, _P, _P, _P, _P, _P]
+        L.rtc_render_device_noalloc.argtypes = L.rtc_render_device.argtypes
         L.rtc_quantize_device.argtypes = [_P, C.c_int32, C.c_int32, C.c_double, _P, _P]
         L.rtc_scatter_tiles_device.argtypes = [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P]
         L.rtc_scene_build_bvh_device.argtypes = [_P]
@@ -304,10 +305,12 @@ class Scene(object):
         return rgb, ids
 
     def render_device(self, cam, rgb_ptr, ids_ptr=None, rays_ptr=None, tile_ids_ptr=None, n_tiles=0, precision="fp64",
-                      max_depth=5, tile_size=32, shade_eps=0.0, seed=0, stream=None, count_work=False, feedback=True):
-        """Asynchronous launch on device pointers (ints, e.g. torch `tensor.data_ptr()`)."""
+                      max_depth=5, tile_size=32, shade_eps=0.0, seed=0, stream=None, count_work=False, feedback=True, noalloc=False):
+        """Asynchronous launch on device pointers (ints, e.g. torch `tensor.data_ptr()`); noalloc=True goes through
+        rtc_render_device_noalloc (launch-order buffers in the library's own device array, no allocation)."""
         c, o = make_camera(cam), make_opts(precision, max_depth, tile_size, shade_eps, seed, count_work, feedback=feedback)
-        _check(lib().rtc_render_device(self.handle, C.byref(c), C.byref(o), int(n_tiles), _P(tile_ids_ptr or None),
+        fn = lib().rtc_render_device_noalloc if noalloc else lib().rtc_render_device
+        _check(fn(self.handle, C.byref(c), C.byref(o), int(n_tiles), _P(tile_ids_ptr or None),
                                        _P(rgb_ptr), _P(ids_ptr or None), _P(rays_ptr or None), _P(stream or None)))
 
 

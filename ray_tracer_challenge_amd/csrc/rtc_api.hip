@@ -1083,6 +1083,102 @@ int rtc_render_device(rtc_scene* scene, const rtc_camera* cam, const rtc_render_
     return launch(scene, cam, opts, n_tiles, tile_ids_dev, rgb_dev, hit_id_dev, rays_dev, work, static_cast<hipStream_t>(stream));
 }
 
+}  // extern "C"
+
+// ---- the entry point that allocates nothing ----
+// Its launch-order buffers (per-unit wave costs, two order lists) live in a file-scope device array instead of a
+// workspace: RTC_NOALLOC_MAX_UNITS 8x8 pixel blocks at most.  Each GPU holds its own copy of the array at its own
+// address, looked up once per device with hipGetSymbolAddress; host code only ever uses that pointer.
+#define RTC_NOALLOC_MAX_UNITS 65536LL                 /* 4 194 304 pixels */
+#define RTC_NOALLOC_ENTRIES(units) ((((units) + 3 * ((units) / 4 + 64)) + RTC_BLOCK / 64 - 1) / (RTC_BLOCK / 64) * (RTC_BLOCK / 64))
+#define RTC_NOALLOC_MAX_DEVICES 64
+namespace {
+struct NoAllocScratch {
+    uint32_t cost[RTC_NOALLOC_MAX_UNITS];
+    int32_t order[2][RTC_NOALLOC_ENTRIES(RTC_NOALLOC_MAX_UNITS)];
+    int32_t used;
+};
+}  // namespace
+static __device__ __align__(256) unsigned char scratch[sizeof(NoAllocScratch)];
+namespace {
+struct NoAllocState {
+    std::mutex m;
+    NoAllocScratch* ptr = nullptr;        // this device's copy of `scratch`
+    const rtc_scene* scene = nullptr; FbKey key{}; int age = 0, cur = 0; bool valid = false;
+} g_noalloc[RTC_NOALLOC_MAX_DEVICES];
+}  // namespace
+
+extern "C" {
+
+int rtc_render_device_noalloc(rtc_scene* scene, const rtc_camera* cam, const rtc_render_opts* opts, int32_t n_tiles, const int32_t* tile_ids_dev,
+                              double* rgb_dev, int32_t* hit_id_dev, int64_t* rays_dev, void* stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    int T, precision, depth;
+    double eps, eps_rel;
+    if (int rc = check_render_args(scene, cam, opts, &T, &precision, &depth, &eps, &eps_rel)) return rc;
+    if (!rgb_dev) return fail(RTC_ERR_INVALID, "null output buffer");
+    if (scene->device < 0 || scene->device >= RTC_NOALLOC_MAX_DEVICES) return fail(RTC_ERR_LIMIT, "device %d beyond the %d this entry point keeps state for", scene->device, RTC_NOALLOC_MAX_DEVICES);
+    const int tiles_x = (cam->hsize + T - 1) / T, tiles_y = (cam->vsize + T - 1) / T;
+    if (!tile_ids_dev) n_tiles = tiles_x * tiles_y;
+    if (n_tiles < 0) return fail(RTC_ERR_INVALID, "negative tile count");
+    if (n_tiles == 0) return 0;
+    const long long blocks = ((long long)n_tiles * T * T + RTC_BLOCK - 1) / RTC_BLOCK, n_units = blocks * (RTC_BLOCK / 64);
+    if (n_units > RTC_NOALLOC_MAX_UNITS)
+        return fail(RTC_ERR_LIMIT, "%lld pixels in %d tiles: rtc_render_device_noalloc renders at most %lld pixels per call (use rtc_render_device)",
+                    (long long)n_tiles * T * T, n_tiles, RTC_NOALLOC_MAX_UNITS * 64);
+    HIP_TRY(hipSetDevice(scene->device));
+    NoAllocState& st = g_noalloc[scene->device];
+    std::lock_guard<std::mutex> lock(st.m);
+    if (!st.ptr) {                                     // first call on this device (it is current): where its copy of the array lives
+        void* p = nullptr;
+        HIP_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        if (!p) return fail(RTC_ERR_HIP, "hipGetSymbolAddress(scratch) returned no address");
+        st.ptr = static_cast<NoAllocScratch*>(p);
+    }
+    NoAllocScratch* const sp = st.ptr;
+    rtc::DFrame F;
+    F.n_tiles = n_tiles; F.tile_size = T; F.tiles_x = tiles_x; F.tile_ids = tile_ids_dev;
+    F.rgb = rgb_dev; F.hit_id = hit_id_dev; F.rays = reinterpret_cast<unsigned long long*>(rays_dev);
+    const bool prof = rays_dev && opts && (opts->flags & RTC_FLAG_COUNT_WORK);
+    F.work = prof ? reinterpret_cast<unsigned long long*>(rays_dev + 4) : nullptr;
+    F.max_depth = depth; F.seed = opts ? opts->seed : 0;
+    F.order = nullptr; F.cost = nullptr;
+    F.n_units = (int32_t)n_units; F.n_entries = (int32_t)n_units;
+    dim3 grid((unsigned)blocks);
+    const long long n_entries = RTC_NOALLOC_ENTRIES(n_units);
+    const bool feedback = !(opts && (opts->flags & RTC_FLAG_NO_FEEDBACK));
+    bool resort = false;
+    if (feedback) {
+        FbKey key;
+        memset(&key, 0, sizeof(key));
+        key.cam = *cam; key.precision = precision; key.depth = depth; key.tile_size = T; key.n_tiles = n_tiles; key.tile_ids = tile_ids_dev;
+        if (st.scene != scene || memcmp(&key, &st.key, sizeof(key)) != 0) { st.scene = scene; st.key = key; st.age = 0; st.valid = false; }
+        resort = st.age < 2;
+        st.age++;
+        if (resort) {
+            // the array keeps whatever the last call left in it: the costs must start at zero
+            HIP_TRY(hipMemsetAsync(sp->cost, 0, (size_t)n_units * sizeof(uint32_t), stream));
+            F.cost = sp->cost;
+        }
+        if (st.valid) {       // every entry the order kernel wrote, unused ones included (they hold -1): no read-back of how many are used
+            F.order = sp->order[st.cur];
+            F.n_entries = (int32_t)n_entries;
+            grid = dim3((unsigned)(n_entries / (RTC_BLOCK / 64)));
+        }
+    }
+    launch_trace(scene, cam, F, grid, precision, prof, eps, eps_rel, stream);
+    HIP_TRY(hipGetLastError());
+    if (feedback && resort) {
+        const int waves_per_simd = scene->has_csg ? 2 : (precision == 64 ? RTC_WAVES_F64 : RTC_WAVES_F32);
+        hipLaunchKernelGGL(order_kernel, dim3(1), dim3(1024), 0, stream, sp->cost, sp->order[1 - st.cur], (int)n_units, (int)n_entries,
+                           scene->n_cus * 4 * waves_per_simd, g_split4, g_split16, &sp->used);
+        HIP_TRY(hipGetLastError());
+        st.cur = 1 - st.cur;
+        st.valid = true;
+    }
+    return 0;
+}
+
 int rtc_quantize_device(const double* rgb_dev, int32_t hsize, int32_t vsize, double max_component, uint8_t* out_dev, void* stream) {
     if (!rgb_dev || !out_dev || hsize < 1 || vsize < 1) return fail(RTC_ERR_INVALID, "bad argument");
     long long n = (long long)hsize * vsize * 3;
