@@ -71,7 +71,10 @@ def make_camera(cam):
     c = _Camera()
     c.hsize, c.vsize = int(cam.hsize), int(cam.vsize)
     c.half_width, c.half_height, c.pixel_size = float(cam.half_width), float(cam.half_height), float(cam.pixel_size)
-    inv = np.linalg.inv(_a(cam.transform)).reshape(16)
+    if getattr(cam, "inv_transform", None) is not None:
+        inv = np.asarray(cam.inv_transform, dtype=np.float64).reshape(16)
+    else:
+        inv = np.linalg.inv(_a(cam.transform)).reshape(16)
     for i in range(16):
         c.inv_transform[i] = inv[i]
     return c
@@ -140,8 +143,8 @@ class Oracle(object):
         n = fn(C.byref(self.s), *extra, _ptr(o), _ptr(d), cap, _ptr(t), _ptr(node))
         return t[:n].copy(), node[:n].copy()
 
-    def intersect_world(self, o, d):
-        return self._xs(lib().orc_intersect_world, (), o, d)
+    def intersect_world(self, o, d, cap=256):
+        return self._xs(lib().orc_intersect_world, (), o, d, cap)
 
     def intersect(self, obj, o, d):
         """shapes.intersect(obj, ray): `obj` is a scene object or a node index."""

@@ -193,8 +193,11 @@ def make_camera(cam):
     c = CameraDesc()
     c.hsize, c.vsize = int(cam.hsize), int(cam.vsize)
     c.half_width, c.half_height, c.pixel_size = float(cam.half_width), float(cam.half_height), float(cam.pixel_size)
-    t = np.asarray(getattr(cam.transform, "arr", cam.transform), dtype=np.float64)
-    inv = np.linalg.inv(t)[:3, :].reshape(12)      # inverse(cam.transform), renderer.py:747-748
+    if getattr(cam, "inv_transform", None) is not None:       # a camera that states its inverse itself (tests: exact rays)
+        inv = np.asarray(cam.inv_transform, dtype=np.float64).reshape(-1)[:12]
+    else:
+        t = np.asarray(getattr(cam.transform, "arr", cam.transform), dtype=np.float64)
+        inv = np.linalg.inv(t)[:3, :].reshape(12)      # inverse(cam.transform), renderer.py:747-748
     for i in range(12):
         c.inv_transform[i] = inv[i]
     return c

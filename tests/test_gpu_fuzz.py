@@ -14,7 +14,7 @@ objects lost their refraction in fp32), and fp32 cap points of cylinders/cones f
 import numpy as np
 import pytest
 
-from conftest import frac_off_by_more_than_one
+from conftest import explain_mismatches, frac_off_by_more_than_one
 from ray_tracer_challenge_amd import _ffi
 from ray_tracer_challenge_amd import shapes as S
 from ray_tracer_challenge_amd.canvas import color
@@ -129,6 +129,19 @@ def _object(rng, budget):
     return _primitive(rng)
 
 
+def _exact(what, orc, cam, rgb, want, ids=None, leaf=None, ok=None, remaining=5, allowed=0.004):
+    """fp64 against the oracle: every differing pixel must be a tie, a grazing hit, acne or on an edge (SURVEY.md 8d,
+    conftest.explain_mismatches) -- none unexplained -- and those are few."""
+    w, h = rgb.shape[0], rgb.shape[1]
+    xs, ys = np.meshgrid(np.arange(w), np.arange(h), indexing="ij")
+    sel = np.ones((w, h), bool) if ok is None else ok
+    unexplained, classes = explain_mismatches(orc, cam, xs[sel], ys[sel], rgb[sel], want[sel], None if ids is None else ids[sel],
+                                              None if leaf is None else leaf[sel], remaining=remaining)
+    print("%s: differing and explained %s, unexplained %d" % (what, classes, len(unexplained)))
+    assert not unexplained, "%s: pixels that differ from the oracle without being tie / grazing / acne / edge: %s" % (what, unexplained[:12])
+    assert sum(classes.values()) <= allowed * sel.sum() + 1
+
+
 def random_world(seed):
     rng = np.random.default_rng(seed)
     n_objects = [1, 2, 3, 4, 7, 12][seed % 6]
@@ -159,7 +172,8 @@ def test_random_world_matches_oracle(seed, oracle_cls):
     cam, world = random_world(seed)
     xs, ys = np.meshgrid(np.arange(HSIZE), np.arange(VSIZE), indexing="ij")
     px, py = xs.ravel(), ys.ravel()
-    want, leaf, t_hit, rays = oracle_cls(world).render_pixels(cam, px, py)
+    orc = oracle_cls(world)
+    want, leaf, t_hit, rays = orc.render_pixels(cam, px, py)
     want, leaf = want.reshape(HSIZE, VSIZE, 3), leaf.reshape(HSIZE, VSIZE)
     near = (~(np.isfinite(t_hit) & (t_hit > 60.0))).reshape(HSIZE, VSIZE)      # fp32 is not asked to resolve patterns on a floor hundreds of units away
     with _ffi.Scene(compile_scene(world), device=0) as sc:
@@ -171,8 +185,7 @@ def test_random_world_matches_oracle(seed, oracle_cls):
     off = (np.abs(rgb - want).max(axis=2) > 1e-9) & ok
     print("seed %d: fp64 off %d, ids %d, fp32 off>1 %.4f, ids32 %d of %d px" % (seed, off.sum(), (ids != leaf).sum(),
           frac_off_by_more_than_one(f32[ok & near], want[ok & near]), (ids32 != leaf).sum(), off.size))      # shown with -s (tools/fuzz_diag.py digs further)
-    assert off.mean() <= 0.003, "fp64: %d of %d pixels differ from the oracle" % (off.sum(), off.size)
-    assert (ids != leaf).mean() <= 0.003
+    _exact("seed %d" % seed, orc, cam, rgb, want, ids, leaf, ok)
     # rays kind by kind: equal up to the few pixels whose discrete decisions fell differently
     got = [st["rays"][0], st["rays"][1] + st["shadow_rays_culled"], st["rays"][2], st["rays"][3]]
     for g, w in zip(got, [int(v) for v in rays]):
@@ -229,14 +242,14 @@ def test_random_mesh_world(seed, oracle_cls):
     cam = Camera(w, h, 0.9, view_transform(point(0.5, 1.8, -6.0), point(0, 0, 0), vector(0, 1, 0)))
     world = World(lights, objs)
     xs, ys = np.meshgrid(np.arange(w), np.arange(h), indexing="ij")
-    want, leaf, t_hit, _ = oracle_cls(world).render_pixels(cam, xs.ravel(), ys.ravel())
+    orc = oracle_cls(world)
+    want, leaf, t_hit, _ = orc.render_pixels(cam, xs.ravel(), ys.ravel())
     want, leaf = want.reshape(w, h, 3), leaf.reshape(w, h)
     near = (~(np.isfinite(t_hit) & (t_hit > 60.0))).reshape(w, h)
     cs = compile_scene(world)
     with _ffi.Scene(cs, device=0) as sc:
         rgb, ids = sc.render(cam, precision="fp64", want_ids=True)
-        assert (np.abs(rgb - want).max(axis=2) > 1e-9).mean() <= 0.004
-        assert (ids != leaf).mean() <= 0.004
+        _exact("mesh seed %d" % seed, orc, cam, rgb, want, ids, leaf)
         f32, _ = sc.render(cam, precision="fp32")
         assert frac_off_by_more_than_one(f32[near], want[near]) <= 0.02
         tiles = np.sort(rng.choice(6, size=3, replace=False)).astype(np.int32)      # 3 x 2 tiles of 32 x 32 cover 71 x 45
@@ -301,7 +314,8 @@ def test_random_csg_world(seed, oracle_cls):
     cam = Camera(HSIZE, VSIZE, 0.9, view_transform(point(0.3, 2.5, -6.5), point(0, -0.2, 0), vector(0, 1, 0)))
     world = World(lights, objs)
     xs, ys = np.meshgrid(np.arange(HSIZE), np.arange(VSIZE), indexing="ij")
-    want, leaf, t_hit, rays = oracle_cls(world).render_pixels(cam, xs.ravel(), ys.ravel())
+    orc = oracle_cls(world)
+    want, leaf, t_hit, rays = orc.render_pixels(cam, xs.ravel(), ys.ravel())
     want, leaf = want.reshape(HSIZE, VSIZE, 3), leaf.reshape(HSIZE, VSIZE)
     near = (~(np.isfinite(t_hit) & (t_hit > 60.0))).reshape(HSIZE, VSIZE)
     with _ffi.Scene(compile_scene(world), device=0) as sc:
@@ -309,7 +323,7 @@ def test_random_csg_world(seed, oracle_cls):
         f32, _ = sc.render(cam, precision="fp32")
     off = np.abs(rgb - want).max(axis=2) > 1e-9
     print("csg seed %d: fp64 off %d, ids %d, fp32 off>1 %.4f" % (seed, off.sum(), (ids != leaf).sum(), frac_off_by_more_than_one(f32[near], want[near])))
-    assert off.mean() <= 0.004 and (ids != leaf).mean() <= 0.004
+    _exact("csg seed %d" % seed, orc, cam, rgb, want, ids, leaf)
     assert frac_off_by_more_than_one(f32[near], want[near]) <= 0.02
 
 
@@ -326,7 +340,7 @@ def test_random_world_at_other_depths(seed, oracle_cls):
             want = want.reshape(HSIZE, VSIZE, 3)
             st = {}
             rgb, _ = sc.render(cam, precision="fp64", max_depth=depth, stats=st)
-            assert (np.abs(rgb - want).max(axis=2) > 1e-9).mean() <= 0.003, depth
+            _exact("seed %d depth %d" % (seed, depth), orc, cam, rgb, want, remaining=depth)
             if depth == 0:
                 assert st["rays"][2] == 0 and st["rays"][3] == 0
         with pytest.raises(_ffi.RtcError, match="max_depth"):
@@ -367,7 +381,8 @@ def test_random_image_textures(seed, oracle_cls):
     image maximum as the scale) against the oracle."""
     cam, world = random_texture_world(seed)
     xs, ys = np.meshgrid(np.arange(HSIZE), np.arange(VSIZE), indexing="ij")
-    want, leaf, t_hit, _ = oracle_cls(world).render_pixels(cam, xs.ravel(), ys.ravel())
+    orc = oracle_cls(world)
+    want, leaf, t_hit, _ = orc.render_pixels(cam, xs.ravel(), ys.ravel())
     want, leaf = want.reshape(HSIZE, VSIZE, 3), leaf.reshape(HSIZE, VSIZE)
     near = (~(np.isfinite(t_hit) & (t_hit > 60.0))).reshape(HSIZE, VSIZE)
     with _ffi.Scene(compile_scene(world), device=0) as sc:
@@ -377,5 +392,5 @@ def test_random_image_textures(seed, oracle_cls):
     off = (np.abs(rgb - want).max(axis=2) > 1e-9) & ok
     print("tex seed %d: fp64 off %d, ids %d, nan px %d, fp32 off>1 %.4f" % (seed, off.sum(), (ids != leaf).sum(), (~ok).sum(),
           frac_off_by_more_than_one(f32[near & ok], want[near & ok])))
-    assert off.mean() <= 0.004 and (ids != leaf).mean() <= 0.004
+    _exact("tex seed %d" % seed, orc, cam, rgb, want, ids, leaf, ok & np.isfinite(rgb).all(axis=2))
     assert frac_off_by_more_than_one(f32[near & ok], want[near & ok]) <= 0.03      # texel boundaries are everywhere at 64 x 48

@@ -1,13 +1,15 @@
 """Parity of the HIP path (through the C ABI) with the CPU oracle and with the fixtures the
-reference itself rendered.  fp64: colours to 1e-9 and exact hit-leaf ids (the only slack is for
-hits at exactly equal t, where the reference's own order is set-iteration order).  fp32: the
-north_star gate -- every channel within 1/255 after PPM quantisation on >= 99.9 % of pixels."""
+reference itself rendered.  fp64: colours to 1e-9 and exact hit-leaf ids on EVERY pixel that is not
+a tie, a grazing hit, acne or on an edge as SURVEY.md 8d defines them -- each differing pixel is
+classified from the oracle's own hit list (conftest.explain_mismatches) and none may stay
+unexplained.  fp32: the north_star gate -- every channel within 1/255 after PPM quantisation on
+>= 99.9 % of pixels."""
 import ctypes as C
 
 import numpy as np
 import pytest
 
-from conftest import frac_off_by_more_than_one, load_golden, load_pack, ppm_levels
+from conftest import explain_mismatches, frac_off_by_more_than_one, load_golden, load_pack, ppm_levels
 from ray_tracer_challenge_amd import _ffi
 from ray_tracer_challenge_amd.canvas import quantize
 from ray_tracer_challenge_amd.compile import compile_scene
@@ -18,7 +20,7 @@ pytestmark = pytest.mark.gpu
 CASES = [("cover", None, 1), ("csg_test", (192, 192), 1), ("group", None, 1), ("checkered_sphere", (160, 160), 1),
          ("checkered_plane", (160, 160), 1), ("checkered_cylinder", (160, 160), 1), ("align_check_plane", (160, 160), 1),
          ("checkered_cube", (320, 160), 1), ("earth", (320, 160), 1), ("skybox", (320, 160), 1),
-         ("shadow_glamour_shot_nojitter", (240, 96), 1), ("teapot", None, 3), ("dragons", (480, 192), 16),
+         ("shadow_glamour_shot_nojitter", (240, 96), 1), ("teapot", None, 3), ("dragons", (480, 192), 4),
          ("perturbed", (320, 200), 1)]          # perturbed patterns: noise restated from the published algorithm, parity unpinned
 GOLDEN = [c[0] for c in CASES]
 
@@ -58,9 +60,12 @@ def test_fp64_matches_oracle(name, size, stride, scenes, oracle_cls):
     st = {}
     rgb, ids = sc.render(cam, precision="fp64", want_ids=True, stats=st)
     px, py = _sample(cam, stride)
-    want, leaf, t, rays = oracle_cls(world).render_pixels(cam, px, py)
-    np.testing.assert_allclose(rgb[px, py], want, rtol=0, atol=1e-9)
-    assert (ids[px, py] != leaf).mean() <= 0.002
+    orc = oracle_cls(world)
+    want, leaf, t, rays = orc.render_pixels(cam, px, py)
+    unexplained, classes = explain_mismatches(orc, cam, px, py, rgb[px, py], want, ids[px, py], leaf)
+    print("%s: %d pixels, differing and explained: %s" % (name, len(px), classes))
+    assert not unexplained, unexplained[:20]
+    assert sum(classes.values()) <= 0.002 * len(px) + 2
     assert st["rays"][0] == cam.hsize * cam.vsize
     if stride == 1:
         assert _queries(st) == [int(v) for v in rays]          # same rays, kind by kind
@@ -68,15 +73,18 @@ def test_fp64_matches_oracle(name, size, stride, scenes, oracle_cls):
 
 
 @pytest.mark.parametrize("name", GOLDEN)
-def test_fp64_matches_reference_fixture(name, scenes):
+def test_fp64_matches_reference_fixture(name, scenes, oracle_cls):
     g = load_golden(name)
     cam, world, sc = scenes(name)
     cam = cam.resized(g["meta"]["hsize"], g["meta"]["vsize"])
     rgb, ids = sc.render(cam, precision="fp64", want_ids=True)
     got, got_ids = rgb[g["px"], g["py"]], ids[g["px"], g["py"]]
-    np.testing.assert_allclose(got, g["rgb"], rtol=0, atol=1e-9)
-    assert frac_off_by_more_than_one(got, g["rgb"]) == 0.0
-    assert (got_ids != g["hit_leaf"]).mean() <= 0.002
+    # the fixture is the reference's own output; a pixel that differs must be one the oracle (which agrees with the
+    # fixture, tests/test_oracle_golden.py) shows to be a tie / grazing / acne / edge pixel
+    unexplained, classes = explain_mismatches(oracle_cls(world), cam, g["px"], g["py"], got, g["rgb"], got_ids, g["hit_leaf"])
+    assert not unexplained, unexplained[:20]
+    assert sum(classes.values()) <= 0.002 * len(g["px"]) + 1
+    assert frac_off_by_more_than_one(got, g["rgb"]) <= 0.0005
 
 
 @pytest.mark.parametrize("name,size,stride", CASES)
@@ -134,6 +142,24 @@ def test_full_size_properties(scenes):
     sc.render(cam, precision="fp64", max_depth=1, stats=st1)
     assert st0["rays"][2:] == [0, 0] and _queries(st0)[1] == n_lights * shaded_primary
     assert st1["rays"][2] <= st["rays"][2] and st1["rays"][3] <= st["rays"][3] and st1["rays"][2] > 0
+
+
+def test_benched_frame_against_the_oracle(scenes, oracle_cls):
+    """The frame bench.py times -- dragons at 1920x1080, depth 5 -- on an even grid of 2 294 of its pixels against the
+    oracle (brute force over 140 940 triangles): colours, hit ids and every differing pixel classified."""
+    cam, world, sc = scenes("dragons")
+    cam = cam.resized(1920, 1080)
+    rgb, ids = sc.render(cam, precision="fp64", want_ids=True)
+    px, py = _sample(cam, 30)
+    orc = oracle_cls(world)
+    want, leaf, t, _ = orc.render_pixels(cam, px, py)
+    assert len(px) >= 2000 and (leaf >= 0).sum() > 300
+    unexplained, classes = explain_mismatches(orc, cam, px, py, rgb[px, py], want, ids[px, py], leaf)
+    print("dragons 1080p: %d pixels, differing and explained: %s" % (len(px), classes))
+    assert not unexplained, unexplained[:20]
+    assert sum(classes.values()) <= 0.002 * len(px) + 2
+    rgb32, ids32 = sc.render(cam, precision="fp32", want_ids=True)
+    assert frac_off_by_more_than_one(rgb32[px, py], want) <= 0.001
 
 
 def test_instrumented_variant_is_identical(scenes):
@@ -236,8 +262,10 @@ def test_nested_and_blended_patterns_and_nested_csg(oracle_cls):
         st = {}
         got, ids = sc.render(cam, precision="fp64", want_ids=True, stats=st)
         got32, _ = sc.render(cam, precision="fp32")
-    np.testing.assert_allclose(got, want, atol=1e-9)
-    assert (ids != leaf).mean() <= 0.002
+    xs, ys = np.meshgrid(np.arange(cam.hsize), np.arange(cam.vsize), indexing="ij")
+    unexplained, classes = explain_mismatches(oracle_cls(world), cam, xs.ravel(), ys.ravel(), got.reshape(-1, 3), want.reshape(-1, 3), ids.ravel(), leaf.ravel())
+    assert not unexplained, (unexplained[:20], classes)
+    assert sum(classes.values()) <= 0.002 * xs.size
     assert _queries(st) == [int(v) for v in rays]
     # fine stripes / rings / checkers on a plane seen at a grazing angle: fp32 flips the pattern cell on
     # boundary pixels, which is inherent to the precision; this is a torture scene, not a BASELINE config
