@@ -107,6 +107,55 @@ def make(name, yaml_rel, cwd, size, pixels, edit=None, divide=None, procs=8):
     print("%-30s %5d px  %7.1f s reference  max rgb %.3f  hits %d" % (name, len(px), dt, rgb.max(), (leaf >= 0).sum()), flush=True)
 
 
+def _ref_jitter_frame(seed):
+    """One whole frame of the jittered scene on ONE process, pixels in `render`'s order (y outer, x inner,
+    renderer.py:767-771), Python's global RNG seeded with `seed` first (the reference seeds it with 0 when the area
+    light is constructed, renderer.py:934: seed 0 is the frame `render` gives as shipped)."""
+    import random
+    R = _G["mods"]["renderer"]
+    cam, world = _G["cam"], _G["world"]
+    random.seed(seed)
+    out = np.zeros((cam.hsize, cam.vsize, 3))
+    for y in range(cam.vsize):
+        for x in range(cam.hsize):
+            out[x, y] = np.asarray(R.color_at(world, R.ray_for_pixel(cam, x, y)), dtype=np.float64)
+    return out
+
+
+def block_means(frame, b=8):
+    """(w, h, 3) -> (w // b, h // b, 3) means over b x b pixel blocks (ragged edges dropped)."""
+    w, h = frame.shape[0] // b * b, frame.shape[1] // b * b
+    return frame[:w, :h].reshape(w // b, b, h // b, b, 3).mean(axis=(1, 3))
+
+
+def make_jitter(size=(150, 60), seeds=(0, 1, 2, 3, 4, 5, 6, 7)):
+    """shadow_glamour_shot.yml AS SHIPPED (jitter: true, 10 x 10 area light) rendered by the reference's single-process
+    path, once per seed.  The reference's jittered frames are not reproducible pixel for pixel by anything but itself
+    (SURVEY.md 8a L2), so the fixture is statistical: 8 x 8 block means of every seed's frame, their mean and their
+    standard deviation over the seeds (the reference's own seed-to-seed spread)."""
+    mods = rh.import_reference()
+    with rh.chdir(REF):
+        objs = mods["yaml_parser"].yaml_file_to_world_objects(os.path.join(REF, "shadow_glamour_shot/shadow_glamour_shot.yml"))
+    cam = objs["camera"]
+    cam = mods["renderer"].Camera(size[0], size[1], cam.field_of_view, cam.transform)
+    world = mods["renderer"].World(objs["lights"], objs["world"])
+    assert any(getattr(l, "jitter", False) for l in objs["lights"])
+    _G.update(mods=mods, cam=cam, world=world)
+    t0 = time.time()
+    with mp.get_context("fork").Pool(min(8, len(seeds))) as pool:
+        frames = pool.map(_ref_jitter_frame, list(seeds))
+    dt = time.time() - t0
+    means = np.array([block_means(f) for f in frames])
+    meta = {"scene_pack": "shadow_glamour_shot", "source": "shadow_glamour_shot/shadow_glamour_shot.yml (as shipped, jitter: true)",
+            "hsize": size[0], "vsize": size[1], "block": 8, "seeds": list(seeds), "remaining": 5, "reference_seconds": round(dt, 1),
+            "procs": min(8, len(seeds)),
+            "made_by": "oracle/make_golden.py make_jitter: reference color_at per pixel in render()'s order, random.seed(seed) first"}
+    np.savez_compressed(os.path.join(GOLD, "shadow_glamour_shot_jitter.npz"), block_mean=means.mean(axis=0), block_std=means.std(axis=0, ddof=1),
+                        per_seed=means, frame_seed0=frames[0], meta=np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8))
+    print("shadow_glamour_shot_jitter: %d seeds, %.1f s, largest block std over seeds %.5f (1/255 = %.5f)" % (
+        len(seeds), dt, means.std(axis=0, ddof=1).max(), 1 / 255.0), flush=True)
+
+
 def main(which):
     from make_scene_packs import synthetic_faces
     tm = "texture_mapping"
@@ -150,6 +199,7 @@ def main(which):
         px, py = np.concatenate([px, gx.ravel()]), np.concatenate([py, gy.ravel()])
         make("dragons", "bounding_box_images/bounding_boxes.yml", objs_cwd, (480, 192), (px, py), procs=6)
     jobs["dragons"] = dragons
+    jobs["shadow_glamour_shot_jitter"] = make_jitter
 
     for name in (which or list(jobs)):
         jobs[name]()
