@@ -604,3 +604,36 @@ def test_one_scene_handle_rendered_from_two_threads(scenes):
     for t in threads:
         t.join()
     assert not errors, errors
+
+
+def test_jittered_area_light_against_the_reference(scenes):
+    """SURVEY 8d config 3.  shadow_glamour_shot.yml AS SHIPPED (jitter: true, 10 x 10 area light) was rendered by the
+    reference's single-process path for 8 seeds of Python's RNG (oracle/make_golden.py make_jitter ->
+    tests/golden/shadow_glamour_shot_jitter.npz: 8 x 8 block means per seed, their mean and their spread).  The reference's
+    jittered frames are not reproducible pixel for pixel by anything but itself, so the check is statistical: the mean over
+    16 kernel seeds of the kernel's block means is within 1/255 of the reference's mean block means everywhere (the
+    reference's own seed-to-seed spread of a block mean is at most 0.0014, a third of that), and the kernel's noise has
+    the reference's size."""
+    g = load_golden("shadow_glamour_shot_jitter")
+    cam, world, sc = scenes("shadow_glamour_shot")
+    cam = cam.resized(g["meta"]["hsize"], g["meta"]["vsize"])
+    b = g["meta"]["block"]
+
+    def block_means(frame):
+        w, h = frame.shape[0] // b * b, frame.shape[1] // b * b
+        return frame[:w, :h].reshape(w // b, b, h // b, b, 3).mean(axis=(1, 3))
+
+    assert g["block_std"].max() < 1 / 255.0                                  # else the bound below would have to be 3 sigma
+    mine = np.array([block_means(sc.render(cam, precision="fp64", seed=s)[0]) for s in range(16)])
+    assert np.abs(mine.mean(axis=0) - g["block_mean"]).max() < 1 / 255.0
+    assert np.abs(mine.mean(axis=0) - g["block_mean"]).mean() < 0.25 / 255.0
+    # per-seed noise of a block mean: same size as the reference's (both are 100 uniform samples per light cell grid)
+    mine_std, ref_std = mine.std(axis=0, ddof=1), g["block_std"]
+    assert 0.5 * ref_std.mean() < mine_std.mean() < 2.0 * ref_std.mean()
+    # and single frames: every pixel of the reference's seed-0 frame within the penumbra noise of the kernel's frames
+    lo, hi = np.min([sc.render(cam, precision="fp64", seed=s)[0] for s in range(16)], axis=0), None
+    hi = np.max([sc.render(cam, precision="fp64", seed=s)[0] for s in range(16)], axis=0)
+    inside = (g["frame_seed0"] >= lo - 0.08) & (g["frame_seed0"] <= hi + 0.08)
+    assert inside.mean() > 0.999
+    mine32 = np.array([block_means(sc.render(cam, precision="fp32", seed=s)[0]) for s in range(16)])
+    assert np.abs(mine32.mean(axis=0) - g["block_mean"]).max() < 1 / 255.0
