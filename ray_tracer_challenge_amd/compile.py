@@ -115,10 +115,6 @@ class _Compiler(object):
                 first_node, first_leaf = len(self.csg_nodes), len(self.leaf_kind)
                 self._csg_node(obj, m)
                 self.csg_roots.append([first_node, len(self.csg_nodes) - first_node, first_leaf, len(self.leaf_kind)])
-                hits = sum(_MAX_HITS[k] for k in self.leaf_kind[first_leaf:])
-                if hits > 32:
-                    raise NotImplementedError("a CSG object whose leaves can produce %d hits per ray "
-                                              "(limit 32, RTC_MAX_CSG_HITS)" % hits)
         elif name in _KIND:
             self._leaf(obj, name, m, in_csg)
         else:

@@ -396,8 +396,9 @@ int validate(const rtc_scene_desc& d) {
             int k = d.leaf_kind[l];
             max_hits += (k == RTC_PLANE || k == RTC_TRIANGLE) ? 1 : ((k == RTC_SPHERE || k == RTC_CUBE) ? 2 : 4);
         }
-        if (max_hits > RTC_MAX_CSG_HITS)
-            return fail(RTC_ERR_LIMIT, "CSG root %d can produce %d hits per ray, limit %d", i, max_hits, RTC_MAX_CSG_HITS);
+        if (r[1] > RTC_MAX_CSG_STREAM_NODES && max_hits > RTC_MAX_CSG_HITS)      // (such roots are evaluated without a hit list, csg_stream)
+            return fail(RTC_ERR_LIMIT, "CSG root %d nests %d CSG operations over leaves that can produce %d hits per ray: limit %d operations",
+                        i, r[1], max_hits, RTC_MAX_CSG_STREAM_NODES);
     }
     for (int i = 0; i < d.n_csg_nodes; i++) {
         const int32_t* c = d.csg_node + 5 * i;
@@ -538,7 +539,19 @@ int create_impl(const rtc_scene_desc& d, rtc_scene* sc) {
         sc->d_titems = const_cast<int32_t*>(items_dev); sc->n_titems = (int)tprim.size(); sc->n_tris = d.n_tris;
     }
     UP(unbounded_prims, d.unbounded_prim, d.n_unbounded);
-    UP(csg_root, d.csg_root, 4 * (size_t)d.n_csg_roots);
+    {
+        // roots whose leaves could produce more hits on one ray than the per-lane list holds are evaluated without one
+        std::vector<int32_t> roots(d.csg_root, d.csg_root + 4 * (size_t)d.n_csg_roots);
+        for (int i = 0; i < d.n_csg_roots; i++) {
+            int max_hits = 0;
+            for (int l = roots[4 * i + 2]; l < roots[4 * i + 3]; l++) {
+                int k = d.leaf_kind[l];
+                max_hits += (k == RTC_PLANE || k == RTC_TRIANGLE) ? 1 : ((k == RTC_SPHERE || k == RTC_CUBE) ? 2 : 4);
+            }
+            if (max_hits > RTC_MAX_CSG_HITS || getenv("RTC_CSG_STREAM_ALL")) roots[4 * i + 1] |= RTC_CSG_STREAMED;
+        }
+        UP(csg_root, roots.data(), roots.size());
+    }
     UP(csg_node, d.csg_node, 5 * (size_t)d.n_csg_nodes);
     UP(mat_shadow, d.mat_shadow, d.n_materials);
     UP(mat_program, d.mat_program, d.n_materials);

@@ -369,6 +369,58 @@ template <class R> __device__ __noinline__ void csg_hits(const DScene<R>& S, int
     }
 }
 
+// A root whose leaves could produce more than RTC_MAX_CSG_HITS hits on one ray (two groups of a dozen spheres, a CSG
+// over a mesh) has RTC_CSG_STREAMED set in its node count and is evaluated without a list: its intersections are
+// enumerated in sorted order by repeated minimum scans over its leaves -- key (t, leaf, position in the leaf's own hit
+// list), the order a stable sort of the leaves' lists gives -- and each one is passed up the chain of CSG nodes above
+// its leaf, every node keeping its two `in left` / `in right` flags (shapes.py:375-388) in a bit mask.  f(t, leaf) is
+// called for every intersection the root lets through, in order, until it returns true.  Costs (hits + 1) x leaves
+// leaf tests per ray -- the reference tests every leaf too -- and no memory; at most RTC_MAX_CSG_STREAM_NODES nodes.
+#define RTC_CSG_STREAMED 0x40000000
+#define RTC_MAX_CSG_STREAM_NODES 64
+#define RTC_CSG_OPEN 32       /* leaves of one streamed root a ray can be inside of at once (container walk) */
+template <class R> __device__ __forceinline__ bool csg_key_less(R t0, int l0, int k0, R t1, int l1, int k1) {
+    return t0 < t1 || (t0 == t1 && (l0 < l1 || (l0 == l1 && k0 < k1)));
+}
+template <class R, class F> __device__ __noinline__ void csg_stream(const DScene<R>& S, int root, const Ray<R>& ray, F& f) {
+    const int32_t* rt = S.csg_root + 4 * root;
+    const int n0 = rt[0], nn = rt[1] & ~RTC_CSG_STREAMED;
+    unsigned long long boxed = 0, inl = 0, inr = 0;
+    for (int j = 0; j < nn; j++) {
+        const R* m = S.xform + 12 * (size_t)S.csg_node[5 * (n0 + j) + 4];
+        Ray<R> r = {xpoint(m, ray.o), xvector(m, ray.d)};
+        R tmin, tmax;
+        if (box_hit(r, S.csg_bbox + 6 * (n0 + j), S.csg_bbox + 6 * (n0 + j) + 3, tmin, tmax)) boxed |= 1ULL << j;   // shapes.py:367
+    }
+    R pt = R(0); int pl = -1, pk = -1;
+    bool started = false;
+    while (true) {
+        R bt = R(0); int bl = -1, bk = -1;
+        for (int leaf = rt[2]; leaf < rt[3]; leaf++) {
+            R t[4], u, v;
+            const int n = leaf_hits(S, leaf, ray, t, u, v);
+            for (int k = 0; k < n; k++) {
+                if (!(t[k] == t[k])) continue;                                   // NaN (0 * inf, 0 / 0): no place in any order
+                if (started && !csg_key_less(pt, pl, pk, t[k], leaf, k)) continue;
+                if (bl < 0 || csg_key_less(t[k], leaf, k, bt, bl, bk)) { bt = t[k]; bl = leaf; bk = k; }
+            }
+        }
+        if (bl < 0) return;
+        started = true; pt = bt; pl = bl; pk = bk;
+        bool keep = true;
+        for (int j = 0; j < nn && keep; j++) {                                   // children before parents
+            const int32_t* c = S.csg_node + 5 * (n0 + j);
+            if (bl < c[1] || bl >= c[3]) continue;
+            const bool lhit = bl < c[2];
+            const unsigned long long bit = 1ULL << j;
+            keep = (boxed & bit) != 0 && csg_allowed(c[0], lhit, (inl & bit) != 0, (inr & bit) != 0);
+            if (lhit) inl ^= bit; else inr ^= bit;
+        }
+        if (keep && f(bt, bl)) return;
+    }
+}
+__device__ __forceinline__ bool csg_streamed(const int32_t* csg_root, int root) { return (csg_root[4 * root + 1] & RTC_CSG_STREAMED) != 0; }
+
 // ------------------------------------------------------------------------------------------
 // queries over the whole scene
 // ------------------------------------------------------------------------------------------
@@ -503,7 +555,15 @@ template <class R, class CNT> struct NearestVisitor {
     }
     __device__ __forceinline__ bool prim(int32_t code) {
         PrimCode p(code);
-        if (CNT::kCsg && p.kind == RTC_CSG_ROOT) {
+        if (CNT::kCsg && p.kind == RTC_CSG_ROOT && csg_streamed(S.csg_root, p.idx)) {
+            cnt.work(W_CSG);
+            struct First { R t; int leaf; __device__ bool operator()(R tt, int l) { if (tt > R(0)) { t = tt; leaf = l; return true; } return false; } } first = {R(0), -1};
+            csg_stream(S, p.idx, ray, first);
+            if (first.leaf >= 0 && first.t < best) {
+                best = first.t; leaf = first.leaf;
+                if (S.leaf_kind[leaf] == RTC_TRIANGLE) { R t; tri_hit(S.tri_geom + 12 * (size_t)S.leaf_tri[leaf], ray, t, u, v); }
+            }
+        } else if (CNT::kCsg && p.kind == RTC_CSG_ROOT) {
             CsgHits<R> H;
             cnt.work(W_CSG);
             csg_hits(S, p.idx, ray, H);
@@ -541,6 +601,20 @@ template <class R, class CNT> struct ShadowVisitor {
     }
     __device__ __forceinline__ bool prim(int32_t code) {
         PrimCode p(code);
+        if (CNT::kCsg && p.kind == RTC_CSG_ROOT && csg_streamed(S.csg_root, p.idx)) {
+            cnt.work(W_CSG);
+            struct Occluder {
+                const DScene<R>& S; R dist; bool found;
+                __device__ bool operator()(R t, int l) {
+                    if (!(t < dist)) return true;                      // sorted: nothing nearer than the light is left
+                    if (t > R(0) && S.mat_shadow[S.leaf_material[l]]) { found = true; return true; }
+                    return false;
+                }
+            } occ = {S, dist, false};
+            csg_stream(S, p.idx, ray, occ);
+            if (occ.found) { shadowed = true; return true; }
+            return false;
+        }
         if (CNT::kCsg && p.kind == RTC_CSG_ROOT) {
             CsgHits<R> H;
             cnt.work(W_CSG);
@@ -592,6 +666,41 @@ template <class R, class CNT> struct ContainerVisitor {
     }
     __device__ __forceinline__ bool prim(int32_t code) {
         PrimCode p(code);
+        if (CNT::kCsg && p.kind == RTC_CSG_ROOT && csg_streamed(S.csg_root, p.idx)) {
+            cnt.work(W_CSG);
+            // Where the root's sorted list is cut: at X's entry nearest t_hit if X belongs to this root (first pass: its
+            // position among the entries let through), else by value.  Second pass: the reference's `containers` list
+            // itself (renderer.py:224-242) over the entries before the cut -- a leaf met again is taken out, a new one
+            // is appended -- which needs room only for the leaves the ray is inside of at once.
+            int cut = -1;
+            if (x_leaf >= S.csg_root[4 * p.idx + 2] && x_leaf < S.csg_root[4 * p.idx + 3]) {
+                struct Nearest { int x; R t_hit; R gap; int at, seen; __device__ bool operator()(R t, int l) {
+                    if (l == x && abs_(t - t_hit) < gap) { gap = abs_(t - t_hit); at = seen; }
+                    seen++; return false; } } nearest = {x_leaf, t_hit, inf_<R>(), -1, 0};
+                csg_stream(S, p.idx, ray, nearest);
+                cut = nearest.at;
+            }
+            struct Open {
+                R t_hit; int cut, seen, n; int leaf[RTC_CSG_OPEN]; R t[RTC_CSG_OPEN];
+                __device__ bool operator()(R tt, int l) {
+                    if (cut >= 0 ? seen == cut : !(tt < t_hit)) return true;
+                    seen++;
+                    for (int i = 0; i < n; i++)
+                        if (leaf[i] == l) { for (int j = i + 1; j < n; j++) { leaf[j - 1] = leaf[j]; t[j - 1] = t[j]; } n--; return false; }
+                    if (n == RTC_CSG_OPEN) { for (int j = 1; j < n; j++) { leaf[j - 1] = leaf[j]; t[j - 1] = t[j]; } n--; }   // deeper than the list: the oldest goes
+                    leaf[n] = l; t[n] = tt; n++;
+                    return false;
+                }
+            } open;
+            open.t_hit = t_hit; open.cut = cut; open.seen = 0; open.n = 0;
+            csg_stream(S, p.idx, ray, open);
+            bool other = false;
+            for (int i = open.n - 1; i >= 0; i--) {
+                if (open.leaf[i] == x_leaf) account(x_leaf, 1, open.t[i]);
+                else if (!other) { account(open.leaf[i], 1, open.t[i]); other = true; }
+            }
+            return false;
+        }
         if (CNT::kCsg && p.kind == RTC_CSG_ROOT) {
             CsgHits<R> H;
             cnt.work(W_CSG);

@@ -298,12 +298,7 @@ def test_random_csg_world(seed, oracle_cls):
     objs = []
     for k in range(int(rng.integers(1, 4))):
         anchor = translation(*rng.uniform(-1.6, 1.6, 3)) * rotation_x(rng.uniform(0, 6.28)) * rotation_z(rng.uniform(0, 6.28))
-        try:
-            tree = _csg_tree(rng, 2, anchor)
-            compile_scene(World([], [tree]))                               # the 32-hits-per-ray limit
-        except NotImplementedError:
-            continue
-        objs.append(tree)
+        objs.append(_csg_tree(rng, 2, anchor))                              # any size: big ones are evaluated without a hit list
     if not objs or rng.random() < 0.4:
         objs.append(_primitive(rng))
     if rng.random() < 0.7:
@@ -325,6 +320,89 @@ def test_random_csg_world(seed, oracle_cls):
     print("csg seed %d: fp64 off %d, ids %d, fp32 off>1 %.4f" % (seed, off.sum(), (ids != leaf).sum(), frac_off_by_more_than_one(f32[near], want[near])))
     _exact("csg seed %d" % seed, orc, cam, rgb, want, ids, leaf)
     assert frac_off_by_more_than_one(f32[near], want[near]) <= 0.02
+
+
+def _glass(rng):
+    m = _material(rng)
+    m.transparency, m.refractive_index, m.reflective = np.float64(0.7), np.float64(rng.choice([1.33, 1.5])), np.float64(0.2)
+    m.pattern = None
+    return m
+
+
+@pytest.mark.parametrize("case", ["groups_of_spheres", "many_cylinders", "mesh_minus_sphere", "glass_clusters"])
+def test_csg_larger_than_the_hit_list(case, oracle_cls, monkeypatch):
+    """A CSG object whose leaves could put more than 32 intersections on one ray -- two groups of ten spheres, a dozen
+    capped cylinders and cones, a tessellated mesh cut by a sphere, overlapping glass clusters (the refraction container walk
+    inside the CSG) -- used to be refused at rtc_scene_create; the reference renders all of them (CSG.local_intersect over
+    arbitrary groups, shapes.py:366-388).  Such roots are evaluated without a hit list (csg_stream): against the oracle.
+    Then every CSG of an ordinary scene through the same code (RTC_CSG_STREAM_ALL): the same frame bit for bit."""
+    rng = np.random.default_rng({"groups_of_spheres": 1, "many_cylinders": 2, "mesh_minus_sphere": 3, "glass_clusters": 4}[case])
+    _SPREAD[0] = 0.9
+
+    def cluster(n, make):
+        return S.Group(S.Material(), None, [make() for _ in range(n)])
+
+    def ball(mat=None):
+        return S.Sphere(mat or _material(rng), translation(*rng.uniform(-0.9, 0.9, 3)) * scaling(*rng.uniform(0.3, 0.6, 3)))
+    if case == "groups_of_spheres":
+        obj = S.CSG(S.Material(), rotation_y(0.4), S.CSGDifference, cluster(10, ball), cluster(10, ball))
+    elif case == "many_cylinders":
+        def rod():
+            cls = S.Cylinder if rng.random() < 0.6 else S.Cone
+            return cls(_material(rng), translation(*rng.uniform(-0.8, 0.8, 3)) * rotation_x(rng.uniform(0, 3)) * rotation_z(rng.uniform(0, 3)) *
+                       scaling(0.25, 0.8, 0.25), minimum=-1.0, maximum=1.0, closed=True)
+        obj = S.CSG(S.Material(), None, S.CSGUnion, S.CSG(S.Material(), None, S.CSGIntersect, cluster(6, rod), S.Sphere(_material(rng), scaling(1.3, 1.3, 1.3))),
+                    S.CSG(S.Material(), translation(0.3, 0, 0), S.CSGDifference, cluster(5, rod), S.Cube(_material(rng), scaling(0.5, 0.5, 0.5))))
+    elif case == "mesh_minus_sphere":
+        obj = S.CSG(S.Material(), rotation_x(0.3), S.CSGDifference, _mesh(rng, 7, 10, smooth=True),
+                    S.Sphere(_glass(rng), translation(0.5, 0.4, -0.6) * scaling(0.8, 0.8, 0.8)))
+    else:
+        obj = S.CSG(S.Material(), None, S.CSGUnion, cluster(9, lambda: ball(_glass(rng))), cluster(9, lambda: ball(_glass(rng))))
+    floor = S.Plane(_material(rng), translation(0, -2.2, 0))
+    floor.material.transparency = np.float64(0.0)
+    lights = [point_light(point(-4, 6, -5), _rgb(rng, 0.6, 1.0)), point_light(point(5, 3, -4), _rgb(rng, 0.2, 0.5))]
+    cam = Camera(HSIZE, VSIZE, 0.8, view_transform(point(0.4, 1.6, -5.5), point(0, 0, 0), vector(0, 1, 0)))
+    world = World(lights, [obj, floor, ball()])
+    cs = compile_scene(world)
+    assert sum({0: 2, 1: 1, 2: 2, 3: 4, 4: 4, 5: 1}[int(k)] for k in cs.arrays["leaf_kind"][:cs.counts["n_leaves"] - 2]) > 32
+    xs, ys = np.meshgrid(np.arange(HSIZE), np.arange(VSIZE), indexing="ij")
+    orc = oracle_cls(world)
+    want, leaf, t_hit, rays = orc.render_pixels(cam, xs.ravel(), ys.ravel())
+    want, leaf = want.reshape(HSIZE, VSIZE, 3), leaf.reshape(HSIZE, VSIZE)
+    with _ffi.Scene(cs, device=0) as sc:
+        st = {}
+        rgb, ids = sc.render(cam, precision="fp64", want_ids=True, stats=st)
+        f32, _ = sc.render(cam, precision="fp32")
+    _exact("large csg " + case, orc, cam, rgb, want, ids, leaf)
+    assert [st["rays"][0], st["rays"][1] + st["shadow_rays_culled"], st["rays"][2], st["rays"][3]] == [int(v) for v in rays]
+    assert frac_off_by_more_than_one(f32, want) <= 0.02
+    assert (ids >= 0).mean() > 0.2 and len(np.unique(ids)) > 6
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_streamed_csg_equals_listed_csg(seed, monkeypatch):
+    """The two evaluations of a CSG root -- per-lane hit list, and list-free enumeration (csg_stream) -- on the nested CSG
+    worlds of test_random_csg_world (glass and mirror parts included): bit-identical frames, ids and ray counts."""
+    rng = np.random.default_rng(5000 + seed)
+    _SPREAD[0] = 1.0
+    objs = [_csg_tree(rng, 2, translation(*rng.uniform(-1.6, 1.6, 3)) * rotation_x(rng.uniform(0, 6.28))) for _ in range(int(rng.integers(1, 4)))]
+    floor = S.Plane(_material(rng), translation(0, -2.8, 0))
+    floor.material.transparency = np.float64(0.0)
+    world = World([point_light(point(-3, 7, -5), _rgb(rng, 0.5, 1.0))], objs + [floor])
+    cam = Camera(HSIZE, VSIZE, 0.9, view_transform(point(0.3, 2.5, -6.5), point(0, -0.2, 0), vector(0, 1, 0)))
+    cs = compile_scene(world)
+    out = []
+    for stream_all in (False, True):
+        if stream_all:
+            monkeypatch.setenv("RTC_CSG_STREAM_ALL", "1")
+        with _ffi.Scene(cs, device=0) as sc:
+            st = {}
+            rgb, ids = sc.render(cam, precision="fp64", want_ids=True, stats=st)
+            out.append((rgb, ids, st["rays"]))
+    monkeypatch.delenv("RTC_CSG_STREAM_ALL")
+    np.testing.assert_array_equal(out[0][0], out[1][0])
+    np.testing.assert_array_equal(out[0][1], out[1][1])
+    assert out[0][2] == out[1][2]
 
 
 @pytest.mark.parametrize("seed", [4, 8, 11, 18, 20, 22])          # worlds with many reflection / refraction rays
