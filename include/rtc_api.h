@@ -269,6 +269,12 @@ int rtc_quantize_device(const double *rgb_dev, int32_t hsize, int32_t vsize, dou
 int rtc_scatter_tiles_device(const double *tiles_dev, const int32_t *tile_ids_dev, int32_t n_slots, int32_t tile_size,
                              int32_t hsize, int32_t vsize, double *frame_dev, void *stream);
 
+/* The same for the hit-id map: slot k of tiles_dev ([n_slots][tile_size][tile_size] int32, what rtc_render_device writes
+ * to hit_id_dev with a tile list) goes to tile tile_ids_dev[k] of the [x][y] id map (no counterpart in the reference,
+ * which has no id map; renderer.py:819-829 is the canvas side of it). */
+int rtc_scatter_id_tiles_device(const int32_t *tiles_dev, const int32_t *tile_ids_dev, int32_t n_slots, int32_t tile_size,
+                                int32_t hsize, int32_t vsize, int32_t *frame_dev, void *stream);
+
 /* max(canvas) of construct_ppm_body's brightness-scaled variant (canvas.py:137-145, np.max over
  * every component): one double to max_out_dev.  n_values = 3 * hsize * vsize.  Asynchronous. */
 int rtc_frame_max_device(const double *rgb_dev, int64_t n_values, double *max_out_dev, void *stream);

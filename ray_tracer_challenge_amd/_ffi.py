@@ -60,7 +60,7 @@ class SceneInfo(C.Structure):
 
 EXPORTS = ["rtc_version", "rtc_device_count", "rtc_last_error", "rtc_scene_create", "rtc_scene_destroy",
            "rtc_scene_get_info", "rtc_render", "rtc_render_tiles", "rtc_render_device", "rtc_render_device_noalloc", "rtc_quantize_device",
-           "rtc_scatter_tiles_device", "rtc_frame_max_device", "rtc_ppm_body_device", "rtc_ppm_size", "rtc_render_ppm",
+           "rtc_scatter_tiles_device", "rtc_scatter_id_tiles_device", "rtc_frame_max_device", "rtc_ppm_body_device", "rtc_ppm_size", "rtc_render_ppm",
            "rtc_scene_build_bvh_device", "rtc_scene_update_triangles", "rtc_scene_refit_triangles", "rtc_scene_update_triangles_device",
            "rtc_host_alloc", "rtc_host_free"]
 
@@ -110,6 +110,7 @@ def lib():
         L.rtc_render_device_noalloc.argtypes = L.rtc_render_device.argtypes
         L.rtc_quantize_device.argtypes = [_P, C.c_int32, C.c_int32, C.c_double, _P, _P]
         L.rtc_scatter_tiles_device.argtypes = [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P]
+        L.rtc_scatter_id_tiles_device.argtypes = L.rtc_scatter_tiles_device.argtypes
         L.rtc_scene_build_bvh_device.argtypes = [_P]
         L.rtc_scene_update_triangles.argtypes = [_P, C.c_int64, _P, _P]
         L.rtc_scene_refit_triangles.argtypes = [_P, C.c_int64, _P, _P]
@@ -323,6 +324,12 @@ def scatter_tiles_device(tiles_ptr, tile_ids_ptr, n_slots, tile_size, hsize, vsi
                                           _P(frame_ptr), _P(stream or None)))
 
 
+def scatter_id_tiles_device(tiles_ptr, tile_ids_ptr, n_slots, tile_size, hsize, vsize, frame_ptr, stream=None):
+    """Compact hit-id tiles in HBM -> the [x][y] id map in HBM (device pointers as ints)."""
+    _check(lib().rtc_scatter_id_tiles_device(_P(tiles_ptr), _P(tile_ids_ptr), int(n_slots), int(tile_size), int(hsize), int(vsize),
+                                             _P(frame_ptr), _P(stream or None)))
+
+
 def _fill_stats(stats, st):
     if stats is not None:
         stats["rays"] = [int(v) for v in st.rays]
@@ -359,35 +366,66 @@ def scatter_tiles(dst_rgb, dst_ids, tile_ids, rgb_tiles, id_tiles, tile_size=32)
         place(dst_ids, id_tiles, ())
 
 
-def render_on_devices(cs, cam, devices, precision="fp64", max_depth=5, want_ids=False, stats=None, tile_size=32):
-    """One process, several GPUs: tile i goes to devices[i % n] (one host thread per GPU); host-side gather."""
-    if len(devices) == 1:
-        with Scene(cs, device=devices[0]) as sc:
-            return sc.render(cam, precision, max_depth, want_ids, stats)
-    tx, ty = tiles_for(cam.hsize, cam.vsize, tile_size)
-    all_tiles = np.arange(tx * ty, dtype=np.int32)
-    rgb = np.zeros((cam.hsize, cam.vsize, 3), np.float64)
-    ids = np.full((cam.hsize, cam.vsize), -1, np.int32) if want_ids else None
-    total = [0, 0, 0, 0]
-    culled = 0
-    shares = [(dev, all_tiles[k::len(devices)]) for k, dev in enumerate(devices)]
-    shares = [(dev, mine) for dev, mine in shares if mine.size]
+class DeviceScenes(object):
+    """One compiled scene resident on several GPUs -- one `rtc_scene` per device, created and uploaded ONCE -- for any
+    number of frames: tile i of a frame goes to devices[i % n] (one host thread per GPU), host-side gather.  The
+    single-process counterpart of the one-process-per-GPU form in dist.py, for callers without a launcher."""
 
-    def one(share):
-        dev, mine = share
-        st = {}
-        with Scene(cs, device=dev) as sc:
+    def __init__(self, cs, devices):
+        self.devices = list(devices)
+        self.scenes = []
+        try:
+            for d in self.devices:
+                self.scenes.append(Scene(cs, device=d))
+        except Exception:
+            self.close()
+            raise
+
+    def close(self):
+        for sc in self.scenes:
+            sc.close()
+        self.scenes = []
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def render(self, cam, precision="fp64", max_depth=5, want_ids=False, stats=None, tile_size=32):
+        if len(self.scenes) == 1:
+            return self.scenes[0].render(cam, precision, max_depth, want_ids, stats)
+        tx, ty = tiles_for(cam.hsize, cam.vsize, tile_size)
+        all_tiles = np.arange(tx * ty, dtype=np.int32)
+        rgb = np.zeros((cam.hsize, cam.vsize, 3), np.float64)
+        ids = np.full((cam.hsize, cam.vsize), -1, np.int32) if want_ids else None
+        shares = [(sc, all_tiles[k::len(self.scenes)]) for k, sc in enumerate(self.scenes)]
+        shares = [(sc, mine) for sc, mine in shares if mine.size]
+
+        def one(share):
+            sc, mine = share
+            st = {}
             r, i = sc.render_tiles(cam, mine, precision, max_depth, tile_size, want_ids, st)
-        return mine, r, i, st
+            return mine, r, i, st
 
-    from concurrent.futures import ThreadPoolExecutor
-    with ThreadPoolExecutor(max_workers=len(shares)) as pool:      # the C calls release the GIL
-        results = list(pool.map(one, shares))
-    for mine, r, i, st in results:
-        scatter_tiles(rgb, ids, mine, r, i, tile_size)
-        total = [a + b for a, b in zip(total, st["rays"])]
-        culled += st["shadow_rays_culled"]
-    if stats is not None:
-        stats["rays"] = total
-        stats["shadow_rays_culled"] = culled
-    return rgb, ids
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=len(shares)) as pool:      # the C calls release the GIL
+            results = list(pool.map(one, shares))
+        total, culled = [0, 0, 0, 0], 0
+        for mine, r, i, st in results:
+            scatter_tiles(rgb, ids, mine, r, i, tile_size)
+            total = [a + b for a, b in zip(total, st["rays"])]
+            culled += st["shadow_rays_culled"]
+        if stats is not None:
+            stats["rays"] = total
+            stats["shadow_rays_culled"] = culled
+        return rgb, ids
+
+
+def render_on_devices(cs, cam, devices, precision="fp64", max_depth=5, want_ids=False, stats=None, tile_size=32, scenes=None):
+    """One frame on several GPUs of one process.  `scenes` (a DeviceScenes the caller keeps) renders it on scenes that
+    are already resident; without it the scene is created on every device for this call and released after it."""
+    if scenes is not None:
+        return scenes.render(cam, precision, max_depth, want_ids, stats, tile_size)
+    with DeviceScenes(cs, devices) as ds:
+        return ds.render(cam, precision, max_depth, want_ids, stats, tile_size)

@@ -223,6 +223,19 @@ __global__ void scatter_tiles_kernel(const double* tiles, const int32_t* tile_id
     dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2];
 }
 
+// the same for the hit-id map (one int32 per pixel)
+__global__ void scatter_id_tiles_kernel(const int32_t* tiles, const int32_t* tile_ids, int n_slots, int T, int tiles_x, int hsize, int vsize, int32_t* frame) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int per = T * T;
+    if (i >= (long long)n_slots * per) return;
+    int slot = (int)(i / per), within = (int)(i % per);
+    int tile = tile_ids[slot];
+    if (tile < 0) return;
+    int x = (tile % tiles_x) * T + within % T, y = (tile / tiles_x) * T + within / T;
+    if (x >= hsize || y >= vsize) return;
+    frame[(size_t)x * vsize + y] = tiles[i];
+}
+
 // ---------------------------------------------------------------------------------------------
 // device buffers
 // ---------------------------------------------------------------------------------------------
@@ -1290,6 +1303,20 @@ int rtc_scatter_tiles_device(const double* tiles_dev, const int32_t* tile_ids_de
     if ((n + 255) / 256 > 0x7FFFFFFFLL) return fail(RTC_ERR_LIMIT, "too many tiles");
     int tiles_x = (hsize + tile_size - 1) / tile_size;
     hipLaunchKernelGGL(scatter_tiles_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), tiles_dev,
+                       tile_ids_dev, (int)n_slots, (int)tile_size, tiles_x, (int)hsize, (int)vsize, frame_dev);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int rtc_scatter_id_tiles_device(const int32_t* tiles_dev, const int32_t* tile_ids_dev, int32_t n_slots, int32_t tile_size, int32_t hsize,
+                                int32_t vsize, int32_t* frame_dev, void* stream) {
+    if (!tiles_dev || !tile_ids_dev || !frame_dev || n_slots < 0 || hsize < 1 || vsize < 1 || tile_size < 1 || tile_size > 1024)
+        return fail(RTC_ERR_INVALID, "bad argument");
+    if (n_slots == 0) return 0;
+    long long n = (long long)n_slots * tile_size * tile_size;
+    if ((n + 255) / 256 > 0x7FFFFFFFLL) return fail(RTC_ERR_LIMIT, "too many tiles");
+    int tiles_x = (hsize + tile_size - 1) / tile_size;
+    hipLaunchKernelGGL(scatter_id_tiles_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), tiles_dev,
                        tile_ids_dev, (int)n_slots, (int)tile_size, tiles_x, (int)hsize, (int)vsize, frame_dev);
     HIP_TRY(hipGetLastError());
     return 0;

@@ -50,10 +50,11 @@ class FrameGather(object):
     is a single allocation whose per-rank slices the collective receives into; on the CPU (gloo tests)
     it is a torch index copy with the same tile tables."""
 
-    def __init__(self, hsize, vsize, world, rank, device, tile=TILE, group=None):
+    def __init__(self, hsize, vsize, world, rank, device, tile=TILE, group=None, with_ids=False):
         import torch
         self.torch = torch
         self.hsize, self.vsize, self.world, self.rank, self.tile, self.group = hsize, vsize, world, rank, tile, group
+        self.with_ids = with_ids        # also gather the hit-id tiles (a second, 6 x smaller collective) into `self.ids`
         self.mine = rank_tiles(hsize, vsize, world, rank, tile)
         self.per = per = slots_per_rank(hsize, vsize, world, tile)
         self.on_gpu = torch.device(device).type == "cuda"
@@ -76,6 +77,15 @@ class FrameGather(object):
                 self.src, self.dst = torch.from_numpy(src), torch.from_numpy(dst)
         else:
             self.compact = torch.zeros((per, tile, tile, 3), dtype=torch.float64, device=device)
+        self.ids = self.compact_ids = self.all_ids = self.gathered_ids = None
+        if with_ids:
+            if rank == 0:
+                self.ids = torch.full((hsize, vsize), -1, dtype=torch.int32, device=device)
+                self.all_ids = torch.full((world, per, tile, tile), -1, dtype=torch.int32, device=device)
+                self.compact_ids = self.all_ids[0] if world == 1 else torch.full((per, tile, tile), -1, dtype=torch.int32, device=device)
+                self.gathered_ids = [self.all_ids[r] for r in range(world)]
+            else:
+                self.compact_ids = torch.full((per, tile, tile), -1, dtype=torch.int32, device=device)
 
     def scatter(self):
         """rank 0: the gathered tiles -> the canvas."""
@@ -87,6 +97,13 @@ class FrameGather(object):
         else:
             flat = self.all_tiles.reshape(-1, 3)
             self.frame.view(-1, 3).index_copy_(0, self.dst, flat.index_select(0, self.src))
+        if self.with_ids:
+            if self.on_gpu:
+                from . import _ffi
+                _ffi.scatter_id_tiles_device(self.all_ids.data_ptr(), self.slot_tiles.data_ptr(), self.world * self.per, self.tile,
+                                             self.hsize, self.vsize, self.ids.data_ptr(), torch.cuda.current_stream().cuda_stream)
+            else:
+                self.ids.view(-1).index_copy_(0, self.dst, self.all_ids.reshape(-1).index_select(0, self.src))
 
     def gather(self):
         """After this rank's tiles are in `self.compact`: returns the canvas tensor on rank 0, None elsewhere."""
@@ -94,6 +111,8 @@ class FrameGather(object):
         if self.world > 1:
             import torch.distributed as dist
             dist.gather(self.compact, self.gathered if self.rank == 0 else None, dst=0, group=self.group)
+            if self.with_ids:
+                dist.gather(self.compact_ids, self.gathered_ids if self.rank == 0 else None, dst=0, group=self.group)
             if self.rank != 0:
                 return None
         self.scatter()
@@ -109,14 +128,15 @@ class FramePipeline(object):
     into again, or by `drain()`.  Every frame is whole when `drain()` returns; what changes is that the
     xGMI transfer no longer sits between two frames' kernels."""
 
-    def __init__(self, hsize, vsize, world, rank, device, tile=TILE, group=None):
-        self.sets = [FrameGather(hsize, vsize, world, rank, device, tile, group) for _ in range(2)]
+    def __init__(self, hsize, vsize, world, rank, device, tile=TILE, group=None, with_ids=False):
+        self.sets = [FrameGather(hsize, vsize, world, rank, device, tile, group, with_ids) for _ in range(2)]
         self.pending = [None, None]
         self.k = 0
         self.world, self.rank = world, rank
         self.sets[1].tiles_dev = self.sets[0].tiles_dev      # one tile list: the scene's launch-order feedback is keyed by it
         if rank == 0:                       # one canvas: frames are assembled in order
             self.sets[1].frame = self.sets[0].frame
+            self.sets[1].ids = self.sets[0].ids
 
     @property
     def frame(self):
@@ -134,7 +154,10 @@ class FramePipeline(object):
         fg = self.sets[b]
         if self.world > 1:
             import torch.distributed as dist
-            self.pending[b] = dist.gather(fg.compact, fg.gathered if self.rank == 0 else None, dst=0, group=fg.group, async_op=True)
+            work = [dist.gather(fg.compact, fg.gathered if self.rank == 0 else None, dst=0, group=fg.group, async_op=True)]
+            if fg.with_ids:
+                work.append(dist.gather(fg.compact_ids, fg.gathered_ids if self.rank == 0 else None, dst=0, group=fg.group, async_op=True))
+            self.pending[b] = work
         else:
             self.pending[b] = True
         self.k += 1
@@ -145,7 +168,8 @@ class FramePipeline(object):
             return
         self.pending[b] = None
         if work is not True:
-            work.wait()
+            for w in work:
+                w.wait()
         if self.rank == 0:
             self.sets[b].scatter()
 
@@ -157,10 +181,21 @@ class FramePipeline(object):
         return self.frame if self.rank == 0 else None
 
 
+def reduce_counters(rays, group=None):
+    """The 13 ray / work counters every rank's kernels added to (`rays_dev` of rtc_render_device: a torch int64 tensor)
+    summed onto rank 0 -- the `ncclReduce` of SURVEY.md 8e.  In place; other ranks' tensors are left as they were."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.reduce(rays, dst=0, op=dist.ReduceOp.SUM, group=group)
+    return rays
+
+
 def render_distributed(scene, cam, fg, precision="fp64", max_depth=5, rays_ptr=None, stream=None, count_work=False):
-    """One frame: trace this rank's tiles with the HIP kernel into fg.compact, then gather.
-    `scene` is an `_ffi.Scene` on this rank's GPU; `fg` a FrameGather built for `cam`'s size."""
-    scene.render_device(cam, fg.compact.data_ptr(), rays_ptr=rays_ptr, tile_ids_ptr=fg.tiles_dev.data_ptr(),
+    """One frame: trace this rank's tiles with the HIP kernel into fg.compact (and fg.compact_ids if the FrameGather
+    was made with_ids), then gather.  `scene` is an `_ffi.Scene` on this rank's GPU; `fg` a FrameGather built for
+    `cam`'s size.  Ray counters stay per rank until `reduce_counters`."""
+    scene.render_device(cam, fg.compact.data_ptr(), ids_ptr=fg.compact_ids.data_ptr() if fg.with_ids else None,
+                        rays_ptr=rays_ptr, tile_ids_ptr=fg.tiles_dev.data_ptr(),
                         n_tiles=len(fg.mine), precision=precision, max_depth=max_depth, tile_size=fg.tile,
                         stream=stream, count_work=count_work)
     return fg.gather()
@@ -170,7 +205,8 @@ def render_pipelined(scene, cam, pipe, precision="fp64", max_depth=5, rays_ptr=N
     """One frame of a stream of frames: trace this rank's tiles into the pipeline's current buffer set and start its
     gather; the frame is complete after `pipe.drain()` (or once its set comes round again)."""
     fg = pipe.current()
-    scene.render_device(cam, fg.compact.data_ptr(), rays_ptr=rays_ptr, tile_ids_ptr=fg.tiles_dev.data_ptr(),
+    scene.render_device(cam, fg.compact.data_ptr(), ids_ptr=fg.compact_ids.data_ptr() if fg.with_ids else None,
+                        rays_ptr=rays_ptr, tile_ids_ptr=fg.tiles_dev.data_ptr(),
                         n_tiles=len(fg.mine), precision=precision, max_depth=max_depth, tile_size=fg.tile,
                         stream=stream, count_work=count_work)
     pipe.submit()

@@ -178,7 +178,7 @@ def render_ppm(cam, world, precision="fp64", max_depth=5, clamped=True, scaled=T
 
 
 def render_multi(cam, world, num_threads=4, timeout_in_seconds=30, file_path="./", clamping=False,
-                 precision="fp64", max_depth=5, devices=None, return_ids=False, stats=None):
+                 precision="fp64", max_depth=5, devices=None, return_ids=False, stats=None, scenes=None):
     """Same image as `render`, sharded over GPUs (reference renderer.py:795-835).
 
     Returns the raw `(hsize, vsize, 3)` fp64 ndarray like the reference.  `num_threads`
@@ -187,9 +187,15 @@ def render_multi(cam, world, num_threads=4, timeout_in_seconds=30, file_path="./
     partial-image dumps (renderer.py:820-832); a frame here takes milliseconds, so no
     partial image is ever due and they are accepted and ignored.  Any image size is
     accepted (the reference's 2x2 tiling fails on odd sizes; `render` does not).
+    A caller that renders many frames of one world (several cameras, a fly-through) creates
+    `scenes = device_scenes(world, n)` once and passes it to every call: the world is then compiled
+    and uploaded to each GPU once, not once per frame (`world` is ignored in those calls).
     """
     from .compile import compile_scene
     from . import _ffi
+    if scenes is not None:
+        rgb, ids = scenes.render(cam, precision, max_depth, return_ids, stats)
+        return (rgb, ids) if return_ids else rgb
     n_avail = _ffi.device_count()
     if n_avail <= 0:
         raise RuntimeError("render_multi needs at least one GPU (rtc_device_count() = %d)" % n_avail)
@@ -200,3 +206,15 @@ def render_multi(cam, world, num_threads=4, timeout_in_seconds=30, file_path="./
     rgb, ids = _ffi.render_on_devices(cs, cam, list(range(n)), precision=precision,
                                       max_depth=max_depth, want_ids=return_ids, stats=stats)
     return (rgb, ids) if return_ids else rgb
+
+
+def device_scenes(world, devices=None):
+    """`world` compiled once and resident on `devices` GPUs (an int = the first n, default all): a context manager to
+    pass to `render_multi(..., scenes=...)` for many frames of the same world."""
+    from .compile import compile_scene
+    from . import _ffi
+    n_avail = _ffi.device_count()
+    if n_avail <= 0:
+        raise RuntimeError("device_scenes needs at least one GPU (rtc_device_count() = %d)" % n_avail)
+    devs = list(range(n_avail if devices is None else devices)) if not isinstance(devices, (list, tuple)) else list(devices)
+    return _ffi.DeviceScenes(compile_scene(world), devs)

@@ -195,12 +195,19 @@ def test_device_pointer_path_and_quantize_kernel(scenes):
 
 def test_render_api_and_multi(scenes):
     from ray_tracer_challenge_amd.canvas import construct_ppm
-    from ray_tracer_challenge_amd.renderer import render, render_multi
+    from ray_tracer_challenge_amd.renderer import device_scenes, render, render_multi
     cam, world, sc = scenes("cover")
     image = render(cam, world)
     arr = render_multi(cam, world, num_threads=4)
     assert arr.shape == (cam.hsize, cam.vsize, 3) and arr.dtype == np.float64
     np.testing.assert_array_equal(image.np_arr, arr)
+    with device_scenes(world, 1) as resident:                    # many frames of one world: compiled and uploaded once
+        for size in ((100, 100), (64, 48)):
+            c2 = cam.resized(*size)
+            got, ids = render_multi(c2, None, scenes=resident, return_ids=True)
+            ref, ref_ids = sc.render(c2, precision="fp64", want_ids=True)
+            np.testing.assert_array_equal(got, ref)
+            np.testing.assert_array_equal(ids, ref_ids)
     assert len(construct_ppm(image)) == len("P6\n100 100\n255\n") + 3 * 100 * 100 + 1
 
 
@@ -324,20 +331,26 @@ def test_tiles_to_canvas_on_device(scenes):
     from ray_tracer_challenge_amd import dist
     cam, world, sc = scenes("cover")
     cam = cam.resized(150, 70)                                   # ragged: 5 x 3 tiles of 32, the last ones partial
-    want, _ = sc.render(cam, precision="fp64")
+    st = {}
+    want, want_ids = sc.render(cam, precision="fp64", want_ids=True, stats=st)
     dev = torch.device("cuda", 0)
-    fgs = [dist.FrameGather(cam.hsize, cam.vsize, 2, r, dev) for r in range(2)]
+    fgs = [dist.FrameGather(cam.hsize, cam.vsize, 2, r, dev, with_ids=True) for r in range(2)]
     stream = torch.cuda.current_stream().cuda_stream
-    for fg in fgs:
-        sc.render_device(cam, fg.compact.data_ptr(), tile_ids_ptr=fg.tiles_dev.data_ptr(), n_tiles=len(fg.mine), tile_size=fg.tile, stream=stream)
+    counters = [torch.zeros(13, dtype=torch.int64, device=dev) for _ in range(2)]
+    for fg, rays in zip(fgs, counters):
+        sc.render_device(cam, fg.compact.data_ptr(), ids_ptr=fg.compact_ids.data_ptr(), rays_ptr=rays.data_ptr(), tile_ids_ptr=fg.tiles_dev.data_ptr(),
+                         n_tiles=len(fg.mine), tile_size=fg.tile, stream=stream)
     root = fgs[0]
     for r, fg in enumerate(fgs):
-        root.all_tiles[r].copy_(fg.compact)                      # what the RCCL gather does
-    _ffi.scatter_tiles_device(root.all_tiles.data_ptr(), root.slot_tiles.data_ptr(), 2 * root.per, root.tile, cam.hsize, cam.vsize,
-                              root.frame.data_ptr(), stream)
-    got = root.frame
+        root.all_tiles[r].copy_(fg.compact)                      # what the two RCCL gathers do
+        root.all_ids[r].copy_(fg.compact_ids)
+    root.scatter()
     torch.cuda.synchronize()
-    np.testing.assert_array_equal(got.cpu().numpy(), want)
+    np.testing.assert_array_equal(root.frame.cpu().numpy(), want)
+    np.testing.assert_array_equal(root.ids.cpu().numpy(), want_ids)
+    total = (counters[0] + counters[1]).cpu().numpy()            # what dist.reduce_counters leaves on rank 0
+    assert total[1:4].tolist() == st["rays"][1:] and total[12] == st["shadow_rays_culled"]
+    assert total[0] >= cam.hsize * cam.vsize                     # primary rays: every pixel of every (ragged) tile
 
 
 @pytest.mark.parametrize("name,size", [("cover", None), ("shadow_glamour_shot_nojitter", (121, 47))])
