@@ -43,12 +43,13 @@ int fail(int code, const char* fmt, ...) {
 // ---------------------------------------------------------------------------------------------
 // kernels
 // ---------------------------------------------------------------------------------------------
-template <class R, bool PROF, bool CSG>
+// CSG: 0 = the scene has no CSG object and no perturbed pattern, 1 = it has, 2 = and some CSG root is evaluated list-free
+template <class R, bool PROF, int CSG, bool FAR>
 __global__ __launch_bounds__(RTC_BLOCK, (CSG ? 2 : sizeof(R) == 8 ? RTC_WAVES_F64 : RTC_WAVES_F32)) void trace_kernel(rtc::DScene<R> S, rtc::DCamera<R> cam, rtc::DFrame F, R shade_eps, R shade_eps_rel) {
     __shared__ int s_stack[RTC_BVH_STACK * RTC_BLOCK];
     int* stack = s_stack + threadIdx.x;
     const int lane = threadIdx.x & 63;
-    rtc::Counters<PROF, CSG> cnt;
+    rtc::Counters<PROF, (CSG > 0), FAR, (CSG == 2)> cnt;
     rtc::zero_counters(cnt);
     const long long t_start = F.cost ? (long long)wall_clock64() : 0;
     bool lane_on;
@@ -266,14 +267,15 @@ template <class R> std::vector<R> cast_vec(const double* p, size_t n) {
 
 // boxes padded outward so that neither rounding in the compiler nor in the slab test can
 // reject a leaf the leaf test itself would accept
-template <class R> std::vector<R> pad_boxes(const std::vector<double>& box) {
+#define RTC_PAD_OF_EXTENT 8e-7     /* boxes are padded by at least this much of the largest coordinate of the scene (see traverse_bvh) */
+template <class R> std::vector<R> pad_boxes(const std::vector<double>& box, double pad_abs) {
     const double rel = sizeof(R) == 4 ? 2e-5 : 1e-9;
     std::vector<R> out(box.size());
     for (size_t i = 0; i < box.size(); i++) {
         bool is_hi = (i % 6) >= 3;
         double v = box[i];
         if (std::isfinite(v)) {
-            double pad = rel * std::max(1.0, std::fabs(v));
+            double pad = std::max(rel * std::max(1.0, std::fabs(v)), pad_abs);
             v = is_hi ? v + pad : v - pad;
             R r = (R)v;
             if (is_hi && (double)r < v) r = std::nextafter(r, std::numeric_limits<R>::infinity());
@@ -321,7 +323,7 @@ struct rtc_scene {
     DeviceArena mem64, mem32, shared;
     rtc::DScene<double> d64;
     rtc::DScene<float> d32;
-    bool has_jitter = false, has_csg = false;
+    bool has_jitter = false, has_csg = false, has_csg_stream = false;
     std::mutex ws_mutex;      // guards the workspace list
     std::vector<Workspace*> workspaces;
     int n_cus = 0;
@@ -332,6 +334,7 @@ struct rtc_scene {
     DeviceArena tbvh_mem;
     // for refits (same arena): triangle row at each BVH position, parent link of each node, arrival counters
     int32_t* d_tb_row = nullptr; int32_t* d_tparent = nullptr; uint32_t* d_tarrived = nullptr;
+    double max_abs = 0;      // largest coordinate of any box the scene's trees were padded for (RTC_PAD_OF_EXTENT)
     // device-side frame, hit ids, counters and tile list of the host-buffer entry points, kept between calls
     std::mutex out_mutex;
     double* out_rgb = nullptr; int32_t* out_id = nullptr; int64_t* out_rays = nullptr; int32_t* out_tiles = nullptr;
@@ -364,6 +367,38 @@ int upload_real(const rtc_scene_desc& d, const std::vector<double>& node_box, De
     UP_REAL(light_intensity, d.light_intensity, 3 * (size_t)d.n_lights);
 #undef UP_REAL
     (void)node_box;
+    return 0;
+}
+
+// the box of a whole tree = the union of its root's two child boxes (all zero for an empty tree)
+void root_box(const rtc::BvhNode* root, float out[6]) {
+    for (int a = 0; a < 6; a++) out[a] = 0.0f;
+    if (!root) return;
+    bool any = false;
+    for (int side = 0; side < 2; side++) {
+        if (root->child[side] == RTC_EMPTY_CHILD) continue;
+        for (int a = 0; a < 3; a++) {
+            out[a] = any ? std::min(out[a], root->box[6 * side + a]) : root->box[6 * side + a];
+            out[3 + a] = any ? std::max(out[3 + a], root->box[6 * side + 3 + a]) : root->box[6 * side + 3 + a];
+        }
+        any = true;
+    }
+}
+// after a GPU build or refit: the new root boxes come back to the host (64 bytes; the builders have been waited for)
+// *grew: the triangles now reach coordinates the boxes' padding was not made for (the caller pads and builds once more)
+int refresh_triangle_root_box(rtc_scene* sc, bool* grew) {
+    rtc::BvhNode root;
+    HIP_TRY(hipMemcpy(&root, sc->d64.tnodes, sizeof(root), hipMemcpyDeviceToHost));
+    root_box(&root, sc->d64.tbox);
+    memcpy(sc->d32.tbox, sc->d64.tbox, sizeof(sc->d64.tbox));
+    double m = 0;
+    for (int a = 0; a < 6; a++) m = std::max(m, (double)std::fabs(sc->d64.tbox[a]));
+    if (!std::isfinite(m)) return fail(RTC_ERR_INVALID, "triangle rows are not finite");
+    *grew = m > sc->max_abs;
+    if (*grew) {
+        sc->max_abs = 1.5 * m;
+        sc->d64.far_origin = sc->d32.far_origin = (float)(2.0 * sc->max_abs);
+    }
     return 0;
 }
 
@@ -561,7 +596,7 @@ int create_impl(const rtc_scene_desc& d, rtc_scene* sc) {
                 int k = d.leaf_kind[l];
                 max_hits += (k == RTC_PLANE || k == RTC_TRIANGLE) ? 1 : ((k == RTC_SPHERE || k == RTC_CUBE) ? 2 : 4);
             }
-            if (max_hits > RTC_MAX_CSG_HITS || getenv("RTC_CSG_STREAM_ALL")) roots[4 * i + 1] |= RTC_CSG_STREAMED;
+            if (max_hits > RTC_MAX_CSG_HITS || getenv("RTC_CSG_STREAM_ALL")) { roots[4 * i + 1] |= RTC_CSG_STREAMED; sc->has_csg_stream = true; }
         }
         UP(csg_root, roots.data(), roots.size());
     }
@@ -599,8 +634,13 @@ int create_impl(const rtc_scene_desc& d, rtc_scene* sc) {
     CP(tex_off); CP(tex_w); CP(tex_h); CP(tex_data); CP(n_lights); CP(refraction_matters); CP(light_type); CP(light_steps);
 #undef CP
     {
-        auto pack = [](const rtc::Bvh& b) {
-            std::vector<float> boxes = pad_boxes<float>(b.box);
+        double max_abs = 0;
+        for (const rtc::Bvh* b : {&bvh, &tbvh})
+            for (double v : b->box) if (std::isfinite(v)) max_abs = std::max(max_abs, std::fabs(v));
+        sc->max_abs = max_abs;
+        const double pad_abs = RTC_PAD_OF_EXTENT * max_abs;
+        auto pack = [pad_abs](const rtc::Bvh& b) {
+            std::vector<float> boxes = pad_boxes<float>(b.box, pad_abs);
             std::vector<rtc::BvhNode> out((size_t)b.n_nodes());
             for (int i = 0; i < b.n_nodes(); i++) {
                 memcpy(out[i].box, &boxes[12 * (size_t)i], 12 * sizeof(float));
@@ -610,6 +650,10 @@ int create_impl(const rtc_scene_desc& d, rtc_scene* sc) {
             return out;
         };
         std::vector<rtc::BvhNode> on = pack(bvh), tn = pack(tbvh);
+        root_box(on.empty() ? nullptr : &on[0], S.obox);
+        root_box(tn.empty() ? nullptr : &tn[0], S.tbox);
+        memcpy(F.obox, S.obox, sizeof(S.obox)); memcpy(F.tbox, S.tbox, sizeof(S.tbox));
+        S.far_origin = F.far_origin = (float)(2.0 * std::max(max_abs, 1e-30));
         if (int rc = A.upload(on.data(), on.size(), &S.nodes)) return rc;
         if (int rc = sc->tbvh_mem.upload(tn.data(), tn.size(), &S.tnodes)) return rc;
         F.nodes = S.nodes; F.tnodes = S.tnodes;
@@ -660,7 +704,7 @@ int check_render_args(const rtc_scene* scene, const rtc_camera* cam, const rtc_r
 
 // The triangle BVH rebuilt on the GPU from the resident triangle rows (rtc_lbvh.hpp).  Builds into
 // fresh buffers and swaps them in only if the tree fits the traversal stack.
-int rebuild_triangle_bvh_device(rtc_scene* sc) {
+int rebuild_triangle_bvh_device(rtc_scene* sc, bool again = false) {
     const int n = sc->n_titems;
     if (n == 0) return 0;
     const int n_leaves = (n + 1) / 2;
@@ -689,7 +733,8 @@ int rebuild_triangle_bvh_device(rtc_scene* sc) {
     TRY_B(hipMemcpy(p_bounds, bounds_init, sizeof(bounds_init), hipMemcpyHostToDevice));
     const dim3 blk(256);
     auto grid_for = [](long long items) { return dim3((unsigned)((items + 255) / 256)); };
-    hipLaunchKernelGGL(rtc::lbvh_boxes_kernel, grid_for(n), blk, 0, nullptr, n, sc->d_titems, sc->d64.tri_geom, (float*)p_boxes, (uint32_t*)p_bounds);
+    hipLaunchKernelGGL(rtc::lbvh_boxes_kernel, grid_for(n), blk, 0, nullptr, n, sc->d_titems, sc->d64.tri_geom, (float*)p_boxes, (uint32_t*)p_bounds,
+                       RTC_PAD_OF_EXTENT * sc->max_abs);
     int32_t deepest = 0;
     // finest Morton grid first (21 bits per axis); a coarser one if that tree is too deep for the traversal stack
     const int drop_bits[3] = {0, 18, 33};
@@ -739,12 +784,15 @@ int rebuild_triangle_bvh_device(rtc_scene* sc) {
     sc->bvh_nodes = sc->d64.n_bvh_nodes + (int)n_nodes;
     sc->bvh_depth = std::max(sc->obj_depth, (int)deepest);
     sc->bvh_max_leaf = std::max(sc->obj_max_leaf, std::min(n, 2));
+    bool grew = false;
+    if (int rc2 = refresh_triangle_root_box(sc, &grew)) return rc2;
+    if (grew && !again) return rebuild_triangle_bvh_device(sc, true);
     for (Workspace* w : sc->workspaces) w->fb_age = std::min(w->fb_age, 1);   // the launch order stays (any order renders the same image); costs are recorded anew
     return 0;
 }
 
 // The triangle BVH refitted on the GPU: same nodes, same leaves, new boxes around the rows now in the triangle table.
-int refit_triangle_bvh_device(rtc_scene* sc) {
+int refit_triangle_bvh_device(rtc_scene* sc, bool again = false) {
     const int n = sc->n_titems, n_nodes = sc->d64.n_tnodes;
     if (n == 0 || n_nodes == 0) return 0;
     if (!sc->d_tb_row || !sc->d_tparent || !sc->d_tarrived) return fail(RTC_ERR_HIP, "internal: refit tables missing");
@@ -753,9 +801,12 @@ int refit_triangle_bvh_device(rtc_scene* sc) {
     hipLaunchKernelGGL(rtc::bvh_gather_rows_kernel, dim3((unsigned)((12LL * n + 255) / 256)), blk, 0, nullptr, n, (const int32_t*)sc->d_tb_row,
                        sc->d64.tri_geom, sc->d32.tri_geom, const_cast<double*>(sc->d64.tb_geom), const_cast<float*>(sc->d32.tb_geom));
     hipLaunchKernelGGL(rtc::bvh_refit_kernel, dim3((unsigned)((n_nodes + 255) / 256)), blk, 0, nullptr, n_nodes, const_cast<rtc::BvhNode*>(sc->d64.tnodes),
-                       (const int32_t*)sc->d_tparent, sc->d64.tb_geom, sc->d_tarrived);
+                       (const int32_t*)sc->d_tparent, sc->d64.tb_geom, sc->d_tarrived, RTC_PAD_OF_EXTENT * sc->max_abs);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
+    bool grew = false;
+    if (int rc2 = refresh_triangle_root_box(sc, &grew)) return rc2;
+    if (grew && !again) return refit_triangle_bvh_device(sc, true);
     for (Workspace* w : sc->workspaces) w->fb_age = std::min(w->fb_age, 1);
     return 0;
 }
@@ -796,15 +847,17 @@ void launch_trace(const rtc_scene* scene, const rtc_camera* cam, const rtc::DFra
                   hipStream_t stream) {
     const dim3 block(RTC_BLOCK);
     const bool csg = scene->has_csg;
-#define RTC_LAUNCH_TRACE(R, PROF, CSG, SC) \
-    hipLaunchKernelGGL((trace_kernel<R, PROF, CSG>), grid, block, 0, stream, SC, make_camera<R>(*cam), F, (R)eps, (R)eps_rel)
-    if (precision == 64) {
-        if (prof) { if (csg) RTC_LAUNCH_TRACE(double, true, true, scene->d64); else RTC_LAUNCH_TRACE(double, true, false, scene->d64); }
-        else { if (csg) RTC_LAUNCH_TRACE(double, false, true, scene->d64); else RTC_LAUNCH_TRACE(double, false, false, scene->d64); }
-    } else {
-        if (prof) { if (csg) RTC_LAUNCH_TRACE(float, true, true, scene->d32); else RTC_LAUNCH_TRACE(float, true, false, scene->d32); }
-        else { if (csg) RTC_LAUNCH_TRACE(float, false, true, scene->d32); else RTC_LAUNCH_TRACE(float, false, false, scene->d32); }
-    }
+    // a camera farther out than the boxes' padding covers (DScene::far_origin) gets the variants that re-base rays
+    const double far_origin = scene->d64.far_origin;
+    const bool far_cam = std::fabs(cam->inv_transform[3]) > far_origin || std::fabs(cam->inv_transform[7]) > far_origin || std::fabs(cam->inv_transform[11]) > far_origin;
+#define RTC_LAUNCH_TRACE(R, PROF, CSG, SC) do { \
+    if (far_cam) hipLaunchKernelGGL((trace_kernel<R, PROF, CSG, true>), grid, block, 0, stream, SC, make_camera<R>(*cam), F, (R)eps, (R)eps_rel); \
+    else hipLaunchKernelGGL((trace_kernel<R, PROF, CSG, false>), grid, block, 0, stream, SC, make_camera<R>(*cam), F, (R)eps, (R)eps_rel); } while (0)
+#define RTC_LAUNCH_CSG(R, PROF, SC) do { \
+    if (!csg) RTC_LAUNCH_TRACE(R, PROF, 0, SC); else if (!scene->has_csg_stream) RTC_LAUNCH_TRACE(R, PROF, 1, SC); else RTC_LAUNCH_TRACE(R, PROF, 2, SC); } while (0)
+    if (precision == 64) { if (prof) RTC_LAUNCH_CSG(double, true, scene->d64); else RTC_LAUNCH_CSG(double, false, scene->d64); }
+    else { if (prof) RTC_LAUNCH_CSG(float, true, scene->d32); else RTC_LAUNCH_CSG(float, false, scene->d32); }
+#undef RTC_LAUNCH_CSG
 #undef RTC_LAUNCH_TRACE
 }
 

@@ -122,6 +122,8 @@ template <class R> struct DScene {
     const BvhNode* nodes;
     const int32_t* bvh_prims;      // prim codes in BVH leaf order (analytic leaves and CSG roots only)
     // triangles have a BVH of their own whose leaves index tb_* directly (no prim-code indirection):
+    float obox[6], tbox[6];        // the (padded) box of the whole object BVH and of the whole triangle BVH: where far rays are re-based
+    float far_origin;              // 2 x the largest coordinate of any box: a ray that starts beyond it is re-based (traverse_bvh)
     int32_t n_tnodes;
     const BvhNode* tnodes;
     const R* tb_geom;              // [n_tris][12] tri_geom rows in BVH leaf order
@@ -184,8 +186,13 @@ enum { W_NODE = 0, W_TRI = 1, W_LEAF = 2, W_CSG = 3, W_SHADE = 4, W_LIGHT = 5, W
 // CSG = false compiles the CSG branches out of every visitor (scenes without CSG objects then
 // carry none of its per-lane hit lists) and the Perlin noise of perturbed patterns out of the pattern
 // interpreter: the host picks the CSG = true variants for scenes that have either.
-template <bool PROF, bool CSG = true> struct Counters {
+// FAR = the camera is farther from the scene than the boxes' padding covers: rays are re-based where they enter a tree
+// (traverse_bvh); the host picks it from the camera alone, since every other ray starts on a surface of the scene.
+// STREAM = some CSG root of the scene is evaluated list-free (csg_stream): only those scenes' variants carry that code.
+template <bool PROF, bool CSG = true, bool FAR = false, bool STREAM = false> struct Counters {
     static constexpr bool kCsg = CSG;
+    static constexpr bool kFar = FAR;
+    static constexpr bool kStream = CSG && STREAM;
     unsigned int c[5];         // primary, shadow, reflection, refraction rays traced; shadow rays not traced (light behind the surface)
     unsigned int w[PROF ? W_COUNT : 1];
 #ifdef RTC_LANE_STATS   /* development build (tools/lane_stats.py): every counter counts WAVE-level executions, x 65536 */
@@ -448,8 +455,30 @@ __device__ __forceinline__ bool traverse_bvh(const DScene<R>& S, const Ray<R>& r
     if (!(fabsf(ix) <= 1e30f)) ix = copysignf(1e30f, (float)ray.d.x);
     if (!(fabsf(iy) <= 1e30f)) iy = copysignf(1e30f, (float)ray.d.y);
     if (!(fabsf(iz) <= 1e30f)) iz = copysignf(1e30f, (float)ray.d.z);
-    const float ox = -(float)ray.o.x * ix, oy = -(float)ray.o.y * iy, oz = -(float)ray.o.z * iz;
-    const float tlo32 = (float)tlo;
+    // The fp32 slab arithmetic rounds relative to the ray's ORIGIN.  Boxes are padded (pad_boxes) by at least 8e-7 of
+    // the largest coordinate in the scene, which covers rounding an origin of up to twice that size; a ray that starts
+    // farther out (a camera thousands of units from a small mesh) would see the boxes displaced by more than their
+    // padding, so it is re-based, in R, at (just before) the point where it enters the tree's own box: box tests then
+    // run on origin' = origin + base * direction with distances measured from there.  `base` only has to be near the
+    // entry point, not exact, so it is found in fp32.  Only the kernel variants for far cameras (Counters::kFar) carry this:
+    // every other ray of a frame starts on a surface of the scene.  base = 0 changes nothing.
+    float base32 = 0.0f, lim_pad = 0.0f;
+    float ox = -(float)ray.o.x * ix, oy = -(float)ray.o.y * iy, oz = -(float)ray.o.z * iz;
+    float tlo32 = (float)tlo;
+    if (V::Cnt::kFar && fmaxf(fmaxf(fabsf((float)ray.o.x), fabsf((float)ray.o.y)), fabsf((float)ray.o.z)) > S.far_origin) {
+        const float* rb = TRIS ? S.tbox : S.obox;
+        const float px = (float)ray.o.x, py = (float)ray.o.y, pz = (float)ray.o.z;
+        const float x0 = (rb[0] - px) * ix, x1 = (rb[3] - px) * ix, y0 = (rb[1] - py) * iy, y1 = (rb[4] - py) * iy, z0 = (rb[2] - pz) * iz, z1 = (rb[5] - pz) * iz;
+        float enter = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
+        enter -= 1e-3f * fabsf(enter) + 1e-3f;
+        enter = fmaxf(enter, (float)tlo);
+        if (fabsf(enter) < 1e30f) {
+            const R base = R(enter);
+            base32 = enter; lim_pad = 2.4e-7f * fabsf(enter);
+            ox = -(float)(ray.o.x + ray.d.x * base) * ix; oy = -(float)(ray.o.y + ray.d.y * base) * iy; oz = -(float)(ray.o.z + ray.d.z * base) * iz;
+            tlo32 = (float)(tlo - base);
+        }
+    }
     int sp = 0;
     int node = 0;
     while (true) {
@@ -472,7 +501,9 @@ __device__ __forceinline__ bool traverse_bvh(const DScene<R>& S, const Ray<R>& r
                 far[k] = f + fabsf(f) * 1e-5f;
             }
             float lim = (float)vis.limit();
+            if (V::Cnt::kFar) lim -= base32;                    // (float)limit is off by 6e-8 |limit| <= 6e-8 (|base| + |lim|): lim_pad + the relative slack
             lim += fabsf(lim) * 1e-6f;
+            if (V::Cnt::kFar) lim += lim_pad;
             bool h0 = c0 != RTC_EMPTY_CHILD && near[0] <= far[0] && far[0] >= tlo32 && near[0] <= lim;
             bool h1 = c1 != RTC_EMPTY_CHILD && near[1] <= far[1] && far[1] >= tlo32 && near[1] <= lim;
             if (h0 && h1) {
@@ -506,22 +537,25 @@ template <class R, class V> __device__ __forceinline__ void traverse_objects(con
         // (Measured on shadow_glamour_shot: -11 % fp64, -16 % fp32; a per-object box test in front of each leaf test
         // gives all of it back -- the shadow rays of that scene pass through the boxes anyway.  A single object keeps
         // its BVH: there the root's box test spares the background pixels their fp64 leaf test.)
-        if (V::kFlatRootBox) {   // one box around all of them (the root's only child): same conservative fp32 slab test as traverse_bvh's
+        if (V::kFlatRootBox) {   // one box around all of them (the tree's own): the same conservative fp32 slab test as traverse_bvh's
             float ix = 1.0f / (float)ray.d.x, iy = 1.0f / (float)ray.d.y, iz = 1.0f / (float)ray.d.z;
             if (!(fabsf(ix) <= 1e30f)) ix = copysignf(1e30f, (float)ray.d.x);
             if (!(fabsf(iy) <= 1e30f)) iy = copysignf(1e30f, (float)ray.d.y);
             if (!(fabsf(iz) <= 1e30f)) iz = copysignf(1e30f, (float)ray.d.z);
-            const float ox = -(float)ray.o.x * ix, oy = -(float)ray.o.y * iy, oz = -(float)ray.o.z * iz;
-            const float* pb = S.nodes[0].box;
-            float x0 = fmaf(pb[0], ix, ox), x1 = fmaf(pb[3], ix, ox);
-            float y0 = fmaf(pb[1], iy, oy), y1 = fmaf(pb[4], iy, oy);
-            float z0 = fmaf(pb[2], iz, oz), z1 = fmaf(pb[5], iz, oz);
-            float n = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
-            float f = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
-            n -= fabsf(n) * 1e-5f; f += fabsf(f) * 1e-5f;
-            float lim = (float)vis.limit();
-            lim += fabsf(lim) * 1e-6f;
-            if (!(n <= f && f >= (float)tlo && n <= lim)) return;
+            const float* pb = S.obox;
+            const bool far_away = V::Cnt::kFar && fmaxf(fmaxf(fabsf((float)ray.o.x), fabsf((float)ray.o.y)), fabsf((float)ray.o.z)) > S.far_origin;
+            if (!far_away) {     // (a ray from farther out is not culled here: its leaf tests, in R, decide)
+                const float ox = -(float)ray.o.x * ix, oy = -(float)ray.o.y * iy, oz = -(float)ray.o.z * iz;
+                float x0 = fmaf(pb[0], ix, ox), x1 = fmaf(pb[3], ix, ox);
+                float y0 = fmaf(pb[1], iy, oy), y1 = fmaf(pb[4], iy, oy);
+                float z0 = fmaf(pb[2], iz, oz), z1 = fmaf(pb[5], iz, oz);
+                float n = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
+                float f = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
+                n -= fabsf(n) * 1e-5f; f += fabsf(f) * 1e-5f;
+                float lim = (float)vis.limit();
+                lim += fabsf(lim) * 1e-6f;
+                if (!(n <= f && f >= (float)tlo && n <= lim)) return;
+            }
         }
         for (int i = 0; i < S.n_flat_prims; i++)
             if (vis.prim(S.bvh_prims[i])) return;
@@ -539,6 +573,7 @@ template <class R, class V> __device__ __forceinline__ void traverse(const DScen
 
 // hit(intersect_world(ray)) (renderer.py:75-79, shapes.py:1422-1425): smallest t > 0
 template <class R, class CNT> struct NearestVisitor {
+    typedef CNT Cnt;
     const DScene<R>& S; const Ray<R>& ray; CNT& cnt;
     R best; int leaf; R u, v;
     __device__ __forceinline__ NearestVisitor(const DScene<R>& s, const Ray<R>& r, CNT& c) : S(s), ray(r), cnt(c), best(inf_<R>()), leaf(-1), u(0), v(0) {}
@@ -555,7 +590,7 @@ template <class R, class CNT> struct NearestVisitor {
     }
     __device__ __forceinline__ bool prim(int32_t code) {
         PrimCode p(code);
-        if (CNT::kCsg && p.kind == RTC_CSG_ROOT && csg_streamed(S.csg_root, p.idx)) {
+        if (CNT::kStream && p.kind == RTC_CSG_ROOT && csg_streamed(S.csg_root, p.idx)) {
             cnt.work(W_CSG);
             struct First { R t; int leaf; __device__ bool operator()(R tt, int l) { if (tt > R(0)) { t = tt; leaf = l; return true; } return false; } } first = {R(0), -1};
             csg_stream(S, p.idx, ray, first);
@@ -588,6 +623,7 @@ template <class R, class CNT> struct NearestVisitor {
 
 // is_shadowed (renderer.py:552-560): any hit of a shadow-casting leaf with 0 < t < distance
 template <class R, class CNT> struct ShadowVisitor {
+    typedef CNT Cnt;
     const DScene<R>& S; const Ray<R>& ray; CNT& cnt; R dist; bool shadowed;
     __device__ __forceinline__ ShadowVisitor(const DScene<R>& s, const Ray<R>& r, R d, CNT& c) : S(s), ray(r), cnt(c), dist(d), shadowed(false) {}
     static constexpr bool kFlatRootBox = false;    // shadow rays start on the objects: most of them are inside the box anyway
@@ -601,7 +637,7 @@ template <class R, class CNT> struct ShadowVisitor {
     }
     __device__ __forceinline__ bool prim(int32_t code) {
         PrimCode p(code);
-        if (CNT::kCsg && p.kind == RTC_CSG_ROOT && csg_streamed(S.csg_root, p.idx)) {
+        if (CNT::kStream && p.kind == RTC_CSG_ROOT && csg_streamed(S.csg_root, p.idx)) {
             cnt.work(W_CSG);
             struct Occluder {
                 const DScene<R>& S; R dist; bool found;
@@ -639,6 +675,7 @@ template <class R, class CNT> struct ShadowVisitor {
 // order-free pass over every leaf the LINE meets gives: parity and last-t of the hit leaf X,
 // and among the others the odd-parity leaf Y with the largest last-t.
 template <class R, class CNT> struct ContainerVisitor {
+    typedef CNT Cnt;
     const DScene<R>& S; const Ray<R>& ray; CNT& cnt;
     R t_hit; int x_leaf;
     bool x_odd; R x_last;
@@ -666,7 +703,7 @@ template <class R, class CNT> struct ContainerVisitor {
     }
     __device__ __forceinline__ bool prim(int32_t code) {
         PrimCode p(code);
-        if (CNT::kCsg && p.kind == RTC_CSG_ROOT && csg_streamed(S.csg_root, p.idx)) {
+        if (CNT::kStream && p.kind == RTC_CSG_ROOT && csg_streamed(S.csg_root, p.idx)) {
             cnt.work(W_CSG);
             // Where the root's sorted list is cut: at X's entry nearest t_hit if X belongs to this root (first pass: its
             // position among the entries let through), else by value.  Second pass: the reference's `containers` list
@@ -1276,8 +1313,8 @@ template <class R> __device__ __forceinline__ Ray<R> ray_for_pixel(const DCamera
 }
 
 // block-level reduction of the ray / work counters, then a few atomics per block
-template <bool PROF, bool CSG>
-__device__ __forceinline__ void flush_counters(Counters<PROF, CSG>& cnt, const DFrame& F, unsigned int* red /* LDS, >= 5 * RTC_BLOCK/64 */) {
+template <bool PROF, bool CSG, bool FAR, bool STREAM>
+__device__ __forceinline__ void flush_counters(Counters<PROF, CSG, FAR, STREAM>& cnt, const DFrame& F, unsigned int* red /* LDS, >= 5 * RTC_BLOCK/64 */) {
     if (F.rays) {
         __syncthreads();
         for (int k = 0; k < 5; k++) {
@@ -1300,7 +1337,7 @@ __device__ __forceinline__ void flush_counters(Counters<PROF, CSG>& cnt, const D
         }
     }
 }
-template <bool PROF, bool CSG> __device__ __forceinline__ void zero_counters(Counters<PROF, CSG>& cnt) {
+template <bool PROF, bool CSG, bool FAR, bool STREAM> __device__ __forceinline__ void zero_counters(Counters<PROF, CSG, FAR, STREAM>& cnt) {
     for (int k = 0; k < 5; k++) cnt.c[k] = 0;
     for (int k = 0; k < (PROF ? W_COUNT : 1); k++) cnt.w[k] = 0;
 }

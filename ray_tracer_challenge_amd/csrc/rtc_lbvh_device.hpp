@@ -13,7 +13,7 @@ __device__ __forceinline__ float lbvh_unordered(uint32_t o) { return __uint_as_f
 
 // item k = triangle row items[k] & 0x07FFFFFF: its box, padded outward like the host builder's boxes
 // (2e-5 relative, >= 2e-5 absolute, rounded away), and the bounds of all box centres
-__global__ void lbvh_boxes_kernel(int n, const int32_t* items, const double* tri_geom, float* boxes, uint32_t* bounds /* [6] min xyz, max xyz (ordered) */) {
+__global__ void lbvh_boxes_kernel(int n, const int32_t* items, const double* tri_geom, float* boxes, uint32_t* bounds /* [6] min xyz, max xyz (ordered) */, double pad_abs) {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
     const double* g = tri_geom + 12 * (size_t)((uint32_t)items[k] & 0x07FFFFFFu);
@@ -21,7 +21,7 @@ __global__ void lbvh_boxes_kernel(int n, const int32_t* items, const double* tri
     for (int a = 0; a < 3; a++) {
         double p1 = g[a], p2 = g[a] + g[3 + a], p3 = g[a] + g[6 + a];
         double l = fmin(p1, fmin(p2, p3)), h = fmax(p1, fmax(p2, p3));
-        l -= 2e-5 * fmax(1.0, fabs(l)); h += 2e-5 * fmax(1.0, fabs(h));
+        l -= fmax(2e-5 * fmax(1.0, fabs(l)), pad_abs); h += fmax(2e-5 * fmax(1.0, fabs(h)), pad_abs);
         lo[a] = __double2float_rd(l); hi[a] = __double2float_ru(h);
         boxes[6 * (size_t)k + a] = lo[a]; boxes[6 * (size_t)k + 3 + a] = hi[a];
         float c = 0.5f * (lo[a] + hi[a]);
@@ -158,7 +158,7 @@ __global__ void bvh_gather_rows_kernel(int n, const int32_t* row_of, const doubl
 // boxes, and counts itself as arrived; a node is complete once its own thread and the carriers of its inner
 // children have arrived, and whoever arrives last carries the union of its two boxes up into the parent's record.
 // parent[i] = (parent node << 1) | side, -1 for the root; arrived[] zeroed by the caller.
-__global__ void bvh_refit_kernel(int n_nodes, BvhNode* nodes, const int32_t* parent, const double* tb_geom, uint32_t* arrived) {
+__global__ void bvh_refit_kernel(int n_nodes, BvhNode* nodes, const int32_t* parent, const double* tb_geom, uint32_t* arrived, double pad_abs) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_nodes) return;
     for (int side = 0; side < 2; side++) {
@@ -173,7 +173,7 @@ __global__ void bvh_refit_kernel(int n_nodes, BvhNode* nodes, const int32_t* par
                 double p1 = g[a], p2 = g[a] + g[3 + a], p3 = g[a] + g[6 + a];
                 l = fmin(l, fmin(p1, fmin(p2, p3))); h = fmax(h, fmax(p1, fmax(p2, p3)));
             }
-            l -= 2e-5 * fmax(1.0, fabs(l)); h += 2e-5 * fmax(1.0, fabs(h));
+            l -= fmax(2e-5 * fmax(1.0, fabs(l)), pad_abs); h += fmax(2e-5 * fmax(1.0, fabs(h)), pad_abs);
             __hip_atomic_store(slot + a, __double2float_rd(l), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(slot + 3 + a, __double2float_ru(h), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }

@@ -129,14 +129,14 @@ def _object(rng, budget):
     return _primitive(rng)
 
 
-def _exact(what, orc, cam, rgb, want, ids=None, leaf=None, ok=None, remaining=5, allowed=0.004):
+def _exact(what, orc, cam, rgb, want, ids=None, leaf=None, ok=None, remaining=5, allowed=0.004, tol=1e-9):
     """fp64 against the oracle: every differing pixel must be a tie, a grazing hit, acne or on an edge (SURVEY.md 8d,
     conftest.explain_mismatches) -- none unexplained -- and those are few."""
     w, h = rgb.shape[0], rgb.shape[1]
     xs, ys = np.meshgrid(np.arange(w), np.arange(h), indexing="ij")
     sel = np.ones((w, h), bool) if ok is None else ok
     unexplained, classes = explain_mismatches(orc, cam, xs[sel], ys[sel], rgb[sel], want[sel], None if ids is None else ids[sel],
-                                              None if leaf is None else leaf[sel], remaining=remaining)
+                                              None if leaf is None else leaf[sel], remaining=remaining, tol=tol)
     print("%s: differing and explained %s, unexplained %d" % (what, classes, len(unexplained)))
     assert not unexplained, "%s: pixels that differ from the oracle without being tie / grazing / acne / edge: %s" % (what, unexplained[:12])
     assert sum(classes.values()) <= allowed * sel.sum() + 1
@@ -472,3 +472,43 @@ def test_random_image_textures(seed, oracle_cls):
           frac_off_by_more_than_one(f32[near & ok], want[near & ok])))
     _exact("tex seed %d" % seed, orc, cam, rgb, want, ids, leaf, ok & np.isfinite(rgb).all(axis=2))
     assert frac_off_by_more_than_one(f32[near & ok], want[near & ok]) <= 0.03      # texel boundaries are everywhere at 64 x 48
+
+
+@pytest.mark.parametrize("distance", [1.0e3, 1.0e4, 1.0e5])
+def test_camera_far_from_small_geometry(distance, oracle_cls):
+    """The box tests in front of the leaf tests run in fp32 whatever the precision; fp32 arithmetic relative to a ray
+    origin thousands of units away would displace the boxes of unit-sized geometry by more than their padding and could
+    cull hits the leaf test accepts (silently, in fp64 mode too).  Rays are re-based where they enter each tree: a
+    telephoto camera at 1e3, 1e4 and 1e5 units from a unit-sized mesh among a few primitives, off-axis so that no
+    direction component is small by accident, against the oracle: hit ids exact, colours to 1e-6 * max(1, distance / 1e4)^2
+    (seen from D units the reference's own sphere / cylinder discriminants b^2 - 4ac cancel 2 log10(D) digits, so a hit
+    distance carries an absolute error of about 1e-16 D^2 that depends on whether the compiler fused a multiply-add: 1e-8
+    at 1e4, 1e-6 at 1e5; a culled hit would change an id, and a colour by far more).  At 1e5 the oracle's own shading of
+    the small sphere and cylinder is noise near their terminators (the discriminant's error divided by a small sqrt reaches
+    the 1e-4 shadow offset: 2.6 % of the pixels flip between lit and self-shadowed under a 1e-9 rad turn of the camera, in
+    the oracle alone), so the share of explained differences allowed there is 3 %, not 1 %; ids stay exact everywhere."""
+    rng = np.random.default_rng(77)
+    _SPREAD[0] = 0.8
+    objs = [_mesh(rng, 9, 14, smooth=True), S.Sphere(_material(rng), translation(1.4, 0.2, 0.3) * scaling(0.4, 0.4, 0.4)),
+            S.Cube(_material(rng), translation(-1.3, -0.3, 0.2) * rotation_y(0.5) * scaling(0.35, 0.35, 0.35)),
+            S.Cylinder(_material(rng), translation(0.2, -0.9, -0.8) * scaling(0.3, 0.3, 0.3), minimum=-1.0, maximum=1.0, closed=True)]
+    for o in objs[1:]:
+        o.material.pattern = None
+    lights = [point_light(point(-4, 6, -5), _rgb(rng, 0.6, 1.0))]
+    eye = np.array([0.48, 0.31, -0.82]) / np.linalg.norm([0.48, 0.31, -0.82]) * distance
+    fov = 2 * np.arctan(2.4 / distance)
+    cam = Camera(96, 64, fov, view_transform(point(*eye), point(0.05, -0.1, 0), vector(0, 1, 0)))
+    world = World(lights, objs)
+    xs, ys = np.meshgrid(np.arange(cam.hsize), np.arange(cam.vsize), indexing="ij")
+    orc = oracle_cls(world)
+    want, leaf, _, rays = orc.render_pixels(cam, xs.ravel(), ys.ravel())
+    want, leaf = want.reshape(cam.hsize, cam.vsize, 3), leaf.reshape(cam.hsize, cam.vsize)
+    assert (leaf >= 0).mean() > 0.1 and len(np.unique(leaf)) > 50
+    with _ffi.Scene(compile_scene(world), device=0) as sc:
+        rgb, ids = sc.render(cam, precision="fp64", want_ids=True)
+        sc.build_bvh_on_device()                                  # the GPU-built tree re-bases on its own root box
+        rgb2, ids2 = sc.render(cam, precision="fp64", want_ids=True)
+    tol, allowed = 1e-6 * max(1.0, distance / 1e4) ** 2, 0.01 if distance < 1e5 else 0.03
+    assert (ids == leaf).all() and (ids2 == leaf).all()
+    _exact("camera at %g" % distance, orc, cam, rgb, want, ids, leaf, allowed=allowed, tol=tol)
+    _exact("camera at %g, GPU-built tree" % distance, orc, cam, rgb2, want, ids2, leaf, allowed=allowed, tol=tol)
