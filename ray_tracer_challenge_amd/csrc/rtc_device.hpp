@@ -261,6 +261,14 @@ template <class R, bool CONE> __device__ __forceinline__ int quadric_hits(const 
         if (disc < R(0)) return 0;
         R sq = sqrt_(disc);
         R t0 = (-b - sq) / (R(2) * a), t1 = (-b + sq) / (R(2) * a);
+        if (CONE && sizeof(R) == 4) {
+            // fp32 cone: a = dx^2 + dz^2 - dy^2 goes through zero for rays along the cone's side (every view into a cone has
+            // them), where -b -+ sqrt(disc) cancels for one root and the division by a small `a` multiplies what is left of
+            // it.  That root comes from c / q instead (q = -(b + sign(b) sqrt(disc)) / 2, the sum that does not cancel):
+            // same roots, conditioned like a cylinder's.  fp64 stays literal.
+            R q = R(-0.5) * (b + (b < R(0) ? -sq : sq));
+            if (q != R(0)) { t0 = q / a; t1 = c / q; }
+        }
         if (t0 > t1) { R tmp = t0; t0 = t1; t1 = tmp; }
         R y0 = r.o.y + t0 * r.d.y;
         if (minimum < y0 && y0 < maximum) t[n++] = t0;
@@ -1061,9 +1069,6 @@ __device__ __forceinline__ HitCtx<R> make_ctx(const DScene<R>& S, const Ray<R>& 
     // fp32: the hit point carries the rounding of o + d*t, i.e. a few ulp of the larger of |o| and |p|
     R scale = max_(max_(max_(abs_(c.point.x), abs_(c.point.y)), abs_(c.point.z)), max_(max_(abs_(ray.o.x), abs_(ray.o.y)), abs_(ray.o.z)));
     R eps = max_(shade_eps, shade_eps_rel * scale);
-    // fp32 only: a cone's quadratic loses more bits than the other quadrics' (its a, b, c all cancel near the surface), and
-    // a large cone seen from inside showed acne in the random-world runs that a 1e-4 offset removes
-    if (sizeof(R) == 4 && S.leaf_kind[leaf] == RTC_CONE) eps = max_(eps, R(1e-4));
     c.over_point = c.point + c.normalv * eps;
     c.under_point = c.point - c.normalv * eps;
     c.material = S.leaf_material[leaf];

@@ -7,8 +7,9 @@ The oracle is pinned to the reference by tests/test_oracle_golden.py and tests/t
 for inputs the reference never rendered.  Discrete decisions (silhouettes, pattern boundaries, equal-t ties) may fall
 differently within rounding, so a small fraction of pixels may differ; everywhere else fp64 agrees to 1e-9.
 RTC_FUZZ_SEEDS=400 runs more worlds than the default 48 (measured: 395 of 400 with no fp64 pixel off at all, the rest <= 5
-of 3 072; fp32 worst 1.7 % -- floors running to the horizon and transparent cones).  Two defects this test found and that
-are fixed: the n1/n2 container pass counted the hit as its own predecessor when its t was recomputed one ulp lower (glass
+of 3 072).  fp32 has its own test over 200 worlds, test_fp32_gate_over_random_worlds: north_star's gate (at most 0.1 % of
+the pixels more than one 8-bit level off) holds on 97.8 % of 404 worlds measured, and the worlds beyond it are named there
+with their causes.  Two defects this test found and that are fixed: the n1/n2 container pass counted the hit as its own predecessor when its t was recomputed one ulp lower (glass
 objects lost their refraction in fp32), and fp32 cap points of cylinders/cones fell outside the reference's 1e-6 cap test.
 """
 import numpy as np
@@ -190,8 +191,47 @@ def test_random_world_matches_oracle(seed, oracle_cls):
     got = [st["rays"][0], st["rays"][1] + st["shadow_rays_culled"], st["rays"][2], st["rays"][3]]
     for g, w in zip(got, [int(v) for v in rays]):
         assert abs(g - w) <= 0.02 * max(w, 1) + 24
-    assert frac_off_by_more_than_one(f32[ok & near], want[ok & near]) <= 0.02  # fp32: the gate, loosened for 3 072-pixel frames
+    assert frac_off_by_more_than_one(f32[ok & near], want[ok & near]) <= FP32_WORST   # world by world; the gate itself: test_fp32_gate_over_random_worlds
     assert (ids32 != leaf).mean() <= 0.02
+
+
+# fp32 against north_star's gate.  A 64 x 48 frame has 3 072 pixels, so "at most 0.1 % of the pixels more than one 8-bit
+# level off" means at most 3 pixels.  Measured over seeds 0..399 + REGRESSIONS (profiles/r02_fp32_fuzz.txt): 97.8 % of the
+# worlds are within the gate, 99.3 % within twice the gate, the worst is seed 64 at 0.51 %.  The worlds beyond the gate among
+# the first 200 seeds, with what tools/fuzz_diag.py (EPS_SWEEP=1) found on them:
+FP32_BEYOND_GATE = {
+    1:   "a lone SmoothTriangle whose random vertex normals lie almost in its plane: the 1e-5 offset along such a normal lifts the shadow "
+         "ray's origin less than an fp32 ulp of the hit point off the plane, so 7 of its 74 px self-shadow differently (a 1e-4 offset: 0 px)",
+    55:  "the same: a lone mirror SmoothTriangle with near-tangent vertex normals, 7 of 67 px",
+    64:  "a diamond-index (2.417) glass cylinder over a mirror floor: 14 of the 15 px appear at depth >= 2, on refracted rays that leave "
+         "the cylinder at grazing angles where total internal reflection flips within fp32 rounding (depth 0: none off)",
+    92:  "4 px on a glass sphere with a perturbed pattern at depth >= 2; 2 of them move in fp64 too when the offset goes from 1e-6 to 1e-5",
+    155: "4 px inside a large transparent cone, depth >= 1; 2 of them move in fp64 too when the offset goes from 1e-6 to 1e-5 "
+         "(was 1.7 % of the frame before the cone's conditioned solve)",
+}
+FP32_GATE, FP32_WORST = 0.001, 0.006
+
+
+def test_fp32_gate_over_random_worlds(oracle_cls):
+    """fp32 frames of 200 random worlds against the fp64 oracle: at least 95 % of the worlds within north_star's gate, none
+    beyond 0.6 %, and every world beyond the gate is one of those named above (a new one is a regression to look at)."""
+    xs, ys = np.meshgrid(np.arange(HSIZE), np.arange(VSIZE), indexing="ij")
+    share = {}
+    for seed in range(200):
+        cam, world = random_world(seed)
+        want, _, t_hit, _ = oracle_cls(world).render_pixels(cam, xs.ravel(), ys.ravel())
+        want = want.reshape(HSIZE, VSIZE, 3)
+        near = (~(np.isfinite(t_hit) & (t_hit > 60.0))).reshape(HSIZE, VSIZE) & np.isfinite(want).all(axis=2)
+        with _ffi.Scene(compile_scene(world), device=0) as sc:
+            f32, _ = sc.render(cam, precision="fp32")
+        share[seed] = frac_off_by_more_than_one(f32[near], want[near])
+    v = np.array(list(share.values()))
+    beyond = sorted(k for k, f in share.items() if f > FP32_GATE + 1e-4)            # 3 of 3 072 px prints as 0.00098
+    print("fp32 over %d worlds: %.1f %% within the gate, worst %.4f (seed %d); beyond the gate: %s" % (
+        len(v), 100 * (v <= FP32_GATE + 1e-4).mean(), v.max(), int(np.argmax(v)), {k: round(share[k], 4) for k in beyond}))
+    assert (v <= FP32_GATE + 1e-4).mean() >= 0.95
+    assert v.max() <= FP32_WORST
+    assert set(beyond) <= set(FP32_BEYOND_GATE), "worlds newly beyond the fp32 gate: %s" % sorted(set(beyond) - set(FP32_BEYOND_GATE))
 
 
 def _mesh(rng, n_u, n_v, smooth):
@@ -251,7 +291,7 @@ def test_random_mesh_world(seed, oracle_cls):
         rgb, ids = sc.render(cam, precision="fp64", want_ids=True)
         _exact("mesh seed %d" % seed, orc, cam, rgb, want, ids, leaf)
         f32, _ = sc.render(cam, precision="fp32")
-        assert frac_off_by_more_than_one(f32[near], want[near]) <= 0.02
+        assert frac_off_by_more_than_one(f32[near], want[near]) <= 0.005
         tiles = np.sort(rng.choice(6, size=3, replace=False)).astype(np.int32)      # 3 x 2 tiles of 32 x 32 cover 71 x 45
         part, part_ids = sc.render_tiles(cam, tiles, precision="fp64", want_ids=True)
         canvas_rgb, canvas_ids = np.full((w, h, 3), -7.0), np.full((w, h), -7, np.int32)
@@ -319,7 +359,7 @@ def test_random_csg_world(seed, oracle_cls):
     off = np.abs(rgb - want).max(axis=2) > 1e-9
     print("csg seed %d: fp64 off %d, ids %d, fp32 off>1 %.4f" % (seed, off.sum(), (ids != leaf).sum(), frac_off_by_more_than_one(f32[near], want[near])))
     _exact("csg seed %d" % seed, orc, cam, rgb, want, ids, leaf)
-    assert frac_off_by_more_than_one(f32[near], want[near]) <= 0.02
+    assert frac_off_by_more_than_one(f32[near], want[near]) <= 0.004       # 400 CSG worlds: 98.5 % within 0.001, worst 0.0022
 
 
 def _glass(rng):
@@ -375,7 +415,7 @@ def test_csg_larger_than_the_hit_list(case, oracle_cls, monkeypatch):
         f32, _ = sc.render(cam, precision="fp32")
     _exact("large csg " + case, orc, cam, rgb, want, ids, leaf)
     assert [st["rays"][0], st["rays"][1] + st["shadow_rays_culled"], st["rays"][2], st["rays"][3]] == [int(v) for v in rays]
-    assert frac_off_by_more_than_one(f32, want) <= 0.02
+    assert frac_off_by_more_than_one(f32, want) <= 0.005
     assert (ids >= 0).mean() > 0.2 and len(np.unique(ids)) > 6
 
 
@@ -471,7 +511,7 @@ def test_random_image_textures(seed, oracle_cls):
     print("tex seed %d: fp64 off %d, ids %d, nan px %d, fp32 off>1 %.4f" % (seed, off.sum(), (ids != leaf).sum(), (~ok).sum(),
           frac_off_by_more_than_one(f32[near & ok], want[near & ok])))
     _exact("tex seed %d" % seed, orc, cam, rgb, want, ids, leaf, ok & np.isfinite(rgb).all(axis=2))
-    assert frac_off_by_more_than_one(f32[near & ok], want[near & ok]) <= 0.03      # texel boundaries are everywhere at 64 x 48
+    assert frac_off_by_more_than_one(f32[near & ok], want[near & ok]) <= 0.005     # 400 texture worlds: 99 % within 0.001, worst 0.0036 (texel boundaries are everywhere at 64 x 48)
 
 
 @pytest.mark.parametrize("distance", [1.0e3, 1.0e4, 1.0e5])
