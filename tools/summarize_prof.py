@@ -18,17 +18,19 @@ if rows:
     import statistics
     lines += ["", "trace_kernel<double, false, *> per launch, in launch order (us): the first two frames of a view run in plain tile order and",
               "record wave costs, the last launches are bench.py's plain-order comparison; the median is the steady state bench.py times:",
-              " ".join("%.0f" % r for r in rows), "median %.1f us" % statistics.median(rows)]
+              " ".join("%.0f" % r for r in rows[:40]) + (" ... (%d launches)" % len(rows) if len(rows) > 40 else ""),
+              "median %.1f us, mean %.1f us, min %.1f us, max %.1f us over %d launches" % (
+                  statistics.median(rows), statistics.mean(rows), min(rows), max(rows), len(rows))]
 with open(os.path.join(src, "bench_under_rocprof.json")) as f:
     lines += ["", "bench.py JSON line of the same run:", f.read().strip()]
 open(os.path.join("profiles", tag + "_kernel_trace_stats.txt"), "w").write("\n".join(lines) + "\n")
 
-out = ["rocprofv3 --pmc passes (one counter group per run) over python3 bench.py --steps 3 --warmup 1   (%s)" % tag,
+out = ["rocprofv3 --pmc passes (one counter group per run) over python3 bench.py --steps 3 --warmup 1 --min-seconds 0   (%s)" % tag,
        "FETCH_SIZE / WRITE_SIZE are in KiB as rocprofv3 reports them; per MI355X_MICROARCH.md FETCH_SIZE counts 64 B per",
        "128-B request for wide coalesced reads (x2 correction); this kernel's reads are scattered 8..16-B loads, for which",
        "the guide calls the absolute value uncalibrated, so both raw and x2 are given.", ""]
 traffic = {}
-for sub in ("pmc_fetch", "pmc_write", "pmc_sq"):
+for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_mem", "pmc_cache"):
     p = os.path.join(src, sub, "pmc_results.db")
     if not os.path.exists(p):
         continue
