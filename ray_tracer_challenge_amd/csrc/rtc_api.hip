@@ -853,8 +853,12 @@ void launch_trace(const rtc_scene* scene, const rtc_camera* cam, const rtc::DFra
 #define RTC_LAUNCH_TRACE(R, PROF, CSG, SC) do { \
     if (far_cam) hipLaunchKernelGGL((trace_kernel<R, PROF, CSG, true>), grid, block, 0, stream, SC, make_camera<R>(*cam), F, (R)eps, (R)eps_rel); \
     else hipLaunchKernelGGL((trace_kernel<R, PROF, CSG, false>), grid, block, 0, stream, SC, make_camera<R>(*cam), F, (R)eps, (R)eps_rel); } while (0)
+#ifdef RTC_DEV_PLAIN_ONLY   /* development builds (tools/build_variant.sh): only the variants the mesh scenes use -- seconds instead of minutes */
+#define RTC_LAUNCH_CSG(R, PROF, SC) do { (void)csg; hipLaunchKernelGGL((trace_kernel<R, PROF, 0, false>), grid, block, 0, stream, SC, make_camera<R>(*cam), F, (R)eps, (R)eps_rel); } while (0)
+#else
 #define RTC_LAUNCH_CSG(R, PROF, SC) do { \
     if (!csg) RTC_LAUNCH_TRACE(R, PROF, 0, SC); else if (!scene->has_csg_stream) RTC_LAUNCH_TRACE(R, PROF, 1, SC); else RTC_LAUNCH_TRACE(R, PROF, 2, SC); } while (0)
+#endif
     if (precision == 64) { if (prof) RTC_LAUNCH_CSG(double, true, scene->d64); else RTC_LAUNCH_CSG(double, false, scene->d64); }
     else { if (prof) RTC_LAUNCH_CSG(float, true, scene->d32); else RTC_LAUNCH_CSG(float, false, scene->d32); }
 #undef RTC_LAUNCH_CSG

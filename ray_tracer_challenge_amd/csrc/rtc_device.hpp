@@ -287,8 +287,42 @@ template <class R, bool CONE> __device__ __forceinline__ int quadric_hits(const 
     }
     return n;
 }
+// A pointer every active lane holds the same value of, moved to scalar registers (inside a called function even a
+// wave-uniform pointer lives in vector registers): the operand of a scalar load.
+template <class T> __device__ __forceinline__ const T* uniform_ptr(const T* p) {
+    const unsigned long long a = (unsigned long long)p;
+    return reinterpret_cast<const T*>(((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(a >> 32)) << 32) |
+                                      (unsigned int)__builtin_amdgcn_readfirstlane((int)a));
+}
 // shapes.py:812-830 / 860-878 on world-space data; g = p1, e1, e2, det_eps
-template <class R> __device__ __forceinline__ bool tri_hit(const R* __restrict__ g, const Ray<R>& r, R& t, R& u, R& v) {
+template <class R> __device__ __forceinline__ bool tri_hit(const R* __restrict__ g, const Ray<R>& r, R& t, R& u, R& v, bool uniform = false) {
+    // `uniform`: every active lane of the wave tests this same row (traverse_bvh found them at the same leaf): the row
+    // comes through the scalar unit, like the node records
+    R row[10];
+    if (uniform) {
+        const R* g0 = uniform_ptr(g);
+        if (sizeof(R) == 8) {
+            typedef double d8v __attribute__((ext_vector_type(8)));
+            typedef double d2v __attribute__((ext_vector_type(2)));
+            d8v a; d2v b;
+            asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx4 %1, %2, 0x40\n\ts_waitcnt lgkmcnt(0)" : "=s"(a), "=s"(b) : "s"(g0) : "memory");
+#pragma unroll
+            for (int k = 0; k < 8; k++) row[k] = (R)a[k];
+            row[8] = (R)b[0]; row[9] = (R)b[1];
+        } else {
+            typedef float f8v __attribute__((ext_vector_type(8)));
+            typedef float f2v __attribute__((ext_vector_type(2)));
+            f8v a; f2v b;
+            asm volatile("s_load_dwordx8 %0, %2, 0x0\n\ts_load_dwordx2 %1, %2, 0x20\n\ts_waitcnt lgkmcnt(0)" : "=s"(a), "=s"(b) : "s"(g0) : "memory");
+#pragma unroll
+            for (int k = 0; k < 8; k++) row[k] = (R)a[k];
+            row[8] = (R)b[0]; row[9] = (R)b[1];
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 10; k++) row[k] = g[k];
+    }
+    g = row;
     V3<R> p1 = mk<R>(g[0], g[1], g[2]), e1 = mk<R>(g[3], g[4], g[5]), e2 = mk<R>(g[6], g[7], g[8]);
     V3<R> dir_cross_e2 = cross(r.d, e2);
     R det = dot(e1, dir_cross_e2);
@@ -492,8 +526,21 @@ __device__ __forceinline__ bool traverse_bvh(const DScene<R>& S, const Ray<R>& r
     while (true) {
         if (node >= 0) {
             vis.cnt.work(W_NODE);
-            const float4* q = reinterpret_cast<const float4*>(nodes + node);     // 4 x 16-byte loads of one line
-            const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+            // every lane of the wave at the same node (the top of the tree, for the rays of one pixel block): the record
+            // comes through the scalar unit (one 64-byte scalar load) and leaves the vector memory pipe alone
+            float4 q0, q1, q2, q3;
+            const int node0 = __builtin_amdgcn_readfirstlane(node);
+            if (__builtin_amdgcn_ballot_w64(node != node0) == 0ull) {
+                typedef float f16v __attribute__((ext_vector_type(16)));
+                f16v rec;
+                const BvhNode* p0 = uniform_ptr(nodes + node0);
+                asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rec) : "s"(p0) : "memory");
+                q0 = make_float4(rec[0], rec[1], rec[2], rec[3]); q1 = make_float4(rec[4], rec[5], rec[6], rec[7]);
+                q2 = make_float4(rec[8], rec[9], rec[10], rec[11]); q3 = make_float4(rec[12], rec[13], rec[14], rec[15]);
+            } else {
+                const float4* q = reinterpret_cast<const float4*>(nodes + node);
+                q0 = q[0]; q1 = q[1]; q2 = q[2]; q3 = q[3];
+            }
             const float b[12] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w};
             int c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y);
             float near[2], far[2];
@@ -525,8 +572,10 @@ __device__ __forceinline__ bool traverse_bvh(const DScene<R>& S, const Ray<R>& r
         } else {
             int code = ~node;
             int first = code >> 4, count = (code & 15) + 1;
+            bool uniform = false;
+            if (TRIS) uniform = __builtin_amdgcn_ballot_w64(code != __builtin_amdgcn_readfirstlane(code)) == 0ull;
             for (int i = 0; i < count; i++)
-                if (TRIS ? vis.tri(first + i) : vis.prim(S.bvh_prims[first + i])) return true;
+                if (TRIS ? vis.tri(first + i, uniform) : vis.prim(S.bvh_prims[first + i])) return true;
         }
         if (sp == 0) return false;
         sp--;
@@ -588,10 +637,10 @@ template <class R, class CNT> struct NearestVisitor {
     static constexpr bool kFlatRootBox = true;
     __device__ __forceinline__ R limit() const { return best; }
     __device__ __forceinline__ bool done() const { return false; }
-    __device__ __forceinline__ bool tri(int pos) {
+    __device__ __forceinline__ bool tri(int pos, bool uniform = false) {
         R t, tu, tv;
         cnt.work(W_TRI);
-        if (tri_hit(S.tb_geom + 12 * (size_t)pos, ray, t, tu, tv) && t > R(0) && t < best) {
+        if (tri_hit(S.tb_geom + 12 * (size_t)pos, ray, t, tu, tv, uniform) && t > R(0) && t < best) {
             best = t; leaf = S.tb_leaf[pos] & 0x7FFFFFFF; u = tu; v = tv;
         }
         return false;
@@ -637,10 +686,10 @@ template <class R, class CNT> struct ShadowVisitor {
     static constexpr bool kFlatRootBox = false;    // shadow rays start on the objects: most of them are inside the box anyway
     __device__ __forceinline__ R limit() const { return dist; }
     __device__ __forceinline__ bool done() const { return shadowed; }
-    __device__ __forceinline__ bool tri(int pos) {
+    __device__ __forceinline__ bool tri(int pos, bool uniform = false) {
         R t, tu, tv;
         cnt.work(W_TRI);
-        if (tri_hit(S.tb_geom + 12 * (size_t)pos, ray, t, tu, tv) && t > R(0) && t < dist && S.tb_leaf[pos] >= 0) { shadowed = true; return true; }
+        if (tri_hit(S.tb_geom + 12 * (size_t)pos, ray, t, tu, tv, uniform) && t > R(0) && t < dist && S.tb_leaf[pos] >= 0) { shadowed = true; return true; }
         return false;
     }
     __device__ __forceinline__ bool prim(int32_t code) {
@@ -693,7 +742,7 @@ template <class R, class CNT> struct ContainerVisitor {
     static constexpr bool kFlatRootBox = true;
     __device__ __forceinline__ R limit() const { return t_hit; }
     __device__ __forceinline__ bool done() const { return false; }
-    __device__ __forceinline__ bool tri(int pos) {
+    __device__ __forceinline__ bool tri(int pos, bool = false) {
         R t, tu, tv;
         const int leaf = S.tb_leaf[pos] & 0x7FFFFFFF;
         if (leaf == x_leaf) return false;        // the hit triangle's one intersection is the hit itself: nothing precedes it

@@ -1,0 +1,33 @@
+"""A/B of library variants on the mesh scenes (development aid): ab.py variant [variant ...]; `default` = the in-tree library.
+One child process per variant (the library is loaded once per process); prints steady-state kernel ms and frame hashes."""
+import hashlib, os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CASES = [("dragons", 1920, 1080), ("teapot", 1920, 1080), ("earth", 1920, 1080), ("dragons", 480, 192)]
+if len(sys.argv) > 1 and sys.argv[1] == "--child":
+    sys.path.insert(0, ROOT)
+    import numpy as np
+    from ray_tracer_challenge_amd import _ffi
+    from ray_tracer_challenge_amd.compile import compile_scene
+    from ray_tracer_challenge_amd.scene_io import load_world
+    for name, w, h in CASES:
+        cam, world, _ = load_world(os.path.join(ROOT, "scenes", name + ".npz"))
+        cam = cam.resized(w, h)
+        with _ffi.Scene(compile_scene(world)) as sc:
+            row = []
+            for prec in ("fp64", "fp32"):
+                rgb, ids = sc.render(cam, precision=prec, want_ids=True)
+                ms = []
+                for _ in range(12):
+                    st = {}
+                    sc.render(cam, precision=prec, stats=st)
+                    ms.append(st["kernel_ms"])
+                row.append("%s %.3f ms (%s %s)" % (prec, sorted(ms[3:])[len(ms[3:]) // 2], hashlib.sha256(np.ascontiguousarray(rgb).tobytes()).hexdigest()[:8],
+                                                  hashlib.sha256(np.ascontiguousarray(ids).tobytes()).hexdigest()[:8]))
+            print("  %-22s %s" % ("%s@%dx%d" % (name, w, h), "  ".join(row)), flush=True)
+    sys.exit(0)
+for v in sys.argv[1:]:
+    env = dict(os.environ)
+    if v != "default":
+        env["RTC_LIB"] = os.path.join(ROOT, "variants", "librtc_%s.so" % v)
+    print("== %s" % v, flush=True)
+    subprocess.run([sys.executable, os.path.abspath(__file__), "--child"], env=env, check=True, timeout=300)
