@@ -80,13 +80,9 @@ __global__ __launch_bounds__(RTC_BLOCK, (CSG ? 2 : sizeof(R) == 8 ? RTC_WAVES_F6
 
 // Next frame's launch order from this frame's unit costs (one block; n is a few 10^4): entries in
 // descending cost by buckets of a quarter octave -- the launch cannot end before its longest wave
-// does, so the long ones go first.  And when the GPU has more wave slots than work (a rank's share
-// of a frame on many GPUs) the longest wave IS the launch: units whose cost is several times the
-// even share of a slot (total cost / n_slots) are split into four 4x4 quadrant waves (cost >=
-// split4 x share) or sixteen 2x2 waves (>= split16 x share), dearest buckets first, as far as the
-// spare entries go.  A split wave is shorter, not proportionally (measured: about 0.65x for a
-// quadrant), so nothing is split while the GPU is full.  The order inside a bucket is whatever the
-// atomics give; any order and any split render the same image.
+// does, so the long ones go first -- and, from the second measured frame on, with the dearest units
+// split (see order_kernel).  The order inside a bucket is whatever the atomics give; any order and
+// any split render the same image.
 #define RTC_ORDER_BUCKETS 128
 __device__ __forceinline__ int order_bucket(uint32_t c) {
     int lg = 31 - __clz((int)(c | 1u));                              // floor(log2 c)
@@ -98,31 +94,59 @@ __device__ __forceinline__ double order_bucket_floor(int bucket) {     // smalle
     int j = RTC_ORDER_BUCKETS - 1 - bucket, lg = j >> 2, frac = j & 3;
     return lg >= 2 ? (double)(4 + frac) * (double)(1ULL << (lg - 2)) : (double)(1ULL << lg);
 }
-__global__ __launch_bounds__(1024) void order_kernel(const uint32_t* cost, int32_t* order, int n, int n_entries, int n_slots, float split4,
-                                                     float split16, int32_t* used) {
+// Splitting.  A launch cannot end before its longest wave does, and on the mesh scenes the longest waves (blocks of glass and
+// mirror pixels with deep ray trees) run for most of the frame: dragons 1080p fp64, 3 072 wave slots, sum of all wave times
+// / slots = 455 us but the dearest wave alone 700 us.  A unit can be launched as four 4x4-quadrant waves or sixteen 2x2
+// waves instead; a part is shorter than the whole, not proportionally (a wave runs as long as its slowest lane's chain of
+// dependent fetches: part4 ~ 0.65 x, part16 ~ 0.5 x the whole), so splitting buys a shorter critical path with more total
+// wave time.  The rule: for every target T among the bucket ceilings, the buckets above T are split the least that brings
+// their parts under T; the launch is then expected to take max(T, 1.1 x total wave time / slots); the T with the smallest
+// expectation wins (T = the dearest unit: nothing is split).  The same rule serves a full GPU (few units split) and a
+// rank's share of a frame on many GPUs (few waves, so almost everything dear is split).  Parts take their place in the
+// order by their own expected cost.
+__global__ __launch_bounds__(1024) void order_kernel(const uint32_t* cost, int32_t* order, int n, int n_entries, int n_slots, float part4,
+                                                     float part16, int32_t* used, float force_frac) {
     __shared__ unsigned int hist[RTC_ORDER_BUCKETS], cursor[RTC_ORDER_BUCKETS];
+    __shared__ unsigned long long bsum[RTC_ORDER_BUCKETS];
     __shared__ unsigned char ways[RTC_ORDER_BUCKETS];     // 1, 4 or 16 waves for the units of the bucket
     __shared__ unsigned long long total;
-    for (int b = threadIdx.x; b < RTC_ORDER_BUCKETS; b += blockDim.x) { hist[b] = 0; ways[b] = 1; }
+    for (int b = threadIdx.x; b < RTC_ORDER_BUCKETS; b += blockDim.x) { hist[b] = 0; ways[b] = 1; bsum[b] = 0; }
     if (threadIdx.x == 0) total = 0;
     __syncthreads();
     unsigned long long mine = 0;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) { uint32_t c = cost[i]; mine += c; atomicAdd(&hist[order_bucket(c)], 1u); }
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        uint32_t c = cost[i]; mine += c;
+        int b = order_bucket(c);
+        atomicAdd(&hist[b], 1u); atomicAdd(&bsum[b], (unsigned long long)c);
+    }
     atomicAdd(&total, mine);
     __syncthreads();
-    if (threadIdx.x == 0 && split4 > 0.0f) {
-        double share = (double)total / (double)(n_slots > 0 ? n_slots : 1);
-        double from4 = fmax((double)split4 * share, 1000.0), from16 = fmax((double)split16 * share, 4000.0);   // never below 10 / 40 us
-        long long spare = (long long)n_entries - n;
-        for (int b = 0; b < RTC_ORDER_BUCKETS && spare > 0; b++) {            // whole buckets, dearest first, while they fit
-            double floor_cost = order_bucket_floor(b);
-            int k = (split16 > 0.0f && floor_cost >= from16) ? 16 : (floor_cost >= from4 ? 4 : 1);
-            if (k == 1) break;
-            if ((long long)hist[b] * (k - 1) > spare) k = 4;
-            if ((long long)hist[b] * (k - 1) > spare) break;
-            spare -= (long long)hist[b] * (k - 1);
-            ways[b] = (unsigned char)k;
+    if (threadIdx.x == 0 && part4 > 0.0f) {
+        const double slots = (double)(n_slots > 0 ? n_slots : 1), f4 = part4, f16 = part16 > 0.0f ? part16 : 2.0;
+        const long long spare = (long long)n_entries - n;
+        int first = 0;
+        while (first < RTC_ORDER_BUCKETS && hist[first] == 0) first++;
+        double best = 1e300; int best_cut = first;
+        // cut: buckets first .. cut-1 are split, T = ceiling of bucket `cut` (= floor of bucket cut-1; the dearest cost for cut = first)
+        for (int cut = first; cut < RTC_ORDER_BUCKETS; cut++) {
+            const double T = cut == first ? order_bucket_floor(first) * 1.19 : order_bucket_floor(cut - 1);
+            if (T < 1000.0) break;                                              // never below 10 us
+            double sum = (double)total; long long need = 0; bool ok = true;
+            for (int b = first; b < cut && ok; b++) {
+                if (!hist[b]) continue;
+                const double ceil_b = order_bucket_floor(b) * 1.19;             // a quarter octave
+                const int k = ceil_b * f4 <= T ? 4 : 16;
+                if (k == 16 && ceil_b * f16 > T) ok = false;
+                need += (long long)hist[b] * (k - 1);
+                sum += (double)bsum[b] * (k == 4 ? 4.0 * f4 - 1.0 : 16.0 * f16 - 1.0);
+            }
+            if (!ok || need > spare) break;
+            const double est = fmax(T, 1.1 * sum / slots);
+            if (force_frac > 0.0f) { if (T >= force_frac * order_bucket_floor(first) * 1.19) best_cut = cut; continue; }   // development: RTC_SPLIT_T
+            if (est < best * 0.97) { best = est; best_cut = cut; }             // a split has to promise 3 % to be worth doing
         }
+        const double T = best_cut == first ? 1e300 : order_bucket_floor(best_cut - 1);
+        for (int b = first; b < best_cut; b++) ways[b] = (unsigned char)(order_bucket_floor(b) * 1.19 * f4 <= T ? 4 : 16);
     }
     __syncthreads();
     for (int b = threadIdx.x; b < RTC_ORDER_BUCKETS; b += blockDim.x) hist[b] = 0;
@@ -130,7 +154,8 @@ __global__ __launch_bounds__(1024) void order_kernel(const uint32_t* cost, int32
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
         uint32_t c = cost[i];
         unsigned int k = ways[order_bucket(c)];
-        atomicAdd(&hist[order_bucket(c / k)], k);
+        uint32_t pc = k == 1 ? c : (uint32_t)((float)c * (k == 4 ? part4 : part16));
+        atomicAdd(&hist[order_bucket(pc)], k);
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -139,10 +164,13 @@ __global__ __launch_bounds__(1024) void order_kernel(const uint32_t* cost, int32
         total = run;
     }
     __syncthreads();
+    // (Tried: spreading the cheapest workgroups -- sky, a few us each, dispatch-bound at the end of a descending order -- evenly
+    // among the middle ones.  Not faster: every cheap workgroup dispatched earlier delays a dearer one behind it.)
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
         uint32_t c = cost[i];
         unsigned int k = ways[order_bucket(c)];
-        unsigned int at = atomicAdd(&cursor[order_bucket(c / k)], k);
+        uint32_t pc = k == 1 ? c : (uint32_t)((float)c * (k == 4 ? part4 : part16));
+        unsigned int at = atomicAdd(&cursor[order_bucket(pc)], k);
         if (k == 1) order[at] = i * 32;
         else for (unsigned int q = 0; q < k; q++) order[at + q] = i * 32 + (k == 4 ? 1 : 5) + (int)q;
     }
@@ -508,8 +536,9 @@ int validate(const rtc_scene_desc& d) {
 }
 
 // split units dearer than these x (total cost / wave slots) into 4 / 16 waves; 0 = never (development overrides: RTC_SPLIT4, RTC_SPLIT16)
-float g_split4 = [] { const char* e = getenv("RTC_SPLIT4"); return e ? (float)atof(e) : 2.0f; }();
-float g_split16 = [] { const char* e = getenv("RTC_SPLIT16"); return e ? (float)atof(e) : 6.0f; }();
+float g_split4 = [] { const char* e = getenv("RTC_SPLIT4"); return e ? (float)atof(e) : 0.65f; }();     // cost of a 4x4 part / cost of its unit; 0 = never split
+float g_split_t = [] { const char* e = getenv("RTC_SPLIT_T"); return e ? (float)atof(e) : 0.0f; }();
+float g_split16 = [] { const char* e = getenv("RTC_SPLIT16"); return e ? (float)atof(e) : 0.5f; }();     // the same for a 2x2 part
 
 int create_impl(const rtc_scene_desc& d, rtc_scene* sc) {
     {
@@ -944,7 +973,7 @@ int launch(rtc_scene* scene, const rtc_camera* cam, const rtc_render_opts* opts,
         // this frame's costs -> the order the next frame of this view launches in (other buffer: the
         // kernel above may still be reading the current one)
         hipLaunchKernelGGL(order_kernel, dim3(1), dim3(1024), 0, stream, ws->fb_cost, ws->fb_order[1 - ws->fb_cur], (int)n_units,
-                           (int)n_entries, scene->n_cus * 4 * waves_per_simd, g_split4, g_split16, ws->fb_used_dev);
+                           (int)n_entries, scene->n_cus * 4 * waves_per_simd, ws->fb_age >= 2 ? g_split4 : 0.0f, g_split16, ws->fb_used_dev, g_split_t);   // the first measured frame ran in plain order: its costs only sort; the second ran sorted and unsplit: its costs decide the splits
         ws->fb_used_known = false;
         HIP_TRY(hipMemcpyAsync(ws->fb_used_host, ws->fb_used_dev, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipEventRecord(ws->fb_used_event, stream));
@@ -1254,7 +1283,7 @@ int rtc_render_device_noalloc(rtc_scene* scene, const rtc_camera* cam, const rtc
     if (feedback && resort) {
         const int waves_per_simd = scene->has_csg ? 2 : (precision == 64 ? RTC_WAVES_F64 : RTC_WAVES_F32);
         hipLaunchKernelGGL(order_kernel, dim3(1), dim3(1024), 0, stream, sp->cost, sp->order[1 - st.cur], (int)n_units, (int)n_entries,
-                           scene->n_cus * 4 * waves_per_simd, g_split4, g_split16, &sp->used);
+                           scene->n_cus * 4 * waves_per_simd, st.age >= 2 ? g_split4 : 0.0f, g_split16, &sp->used, g_split_t);
         HIP_TRY(hipGetLastError());
         st.cur = 1 - st.cur;
         st.valid = true;

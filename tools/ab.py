@@ -2,7 +2,7 @@
 One child process per variant (the library is loaded once per process); prints steady-state kernel ms and frame hashes."""
 import hashlib, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-CASES = [("dragons", 1920, 1080), ("teapot", 1920, 1080), ("earth", 1920, 1080), ("dragons", 480, 192)]
+CASES = [("dragons", 1920, 1080), ("teapot", 1920, 1080), ("earth", 1920, 1080), ("dragons", 480, 192), ("cover", 1920, 1080), ("shadow_glamour_shot", 1200, 480)]
 if len(sys.argv) > 1 and sys.argv[1] == "--child":
     sys.path.insert(0, ROOT)
     import numpy as np

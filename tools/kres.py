@@ -3,7 +3,7 @@ import os, re, subprocess, sys, tempfile
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "ray_tracer_challenge_amd", "csrc", "rtc_api.hip")
 out = os.path.join(tempfile.gettempdir(), "rtc_k.s")
-subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "--cuda-device-only", "-S", "-o", out, src] + sys.argv[1:],
+subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=on", "--cuda-device-only", "-S", "-o", out, src] + sys.argv[1:],
                check=True, stderr=subprocess.DEVNULL)
 s = open(out).read()
 md = s[s.index("amdhsa.kernels"):]
