@@ -44,21 +44,22 @@ int fail(int code, const char* fmt, ...) {
 // kernels
 // ---------------------------------------------------------------------------------------------
 // CSG: 0 = the scene has no CSG object and no perturbed pattern, 1 = it has, 2 = and some CSG root is evaluated list-free
-template <class R, bool PROF, int CSG, bool FAR>
+// REPL: the pixels of split parts are traced by 4 or 16 lanes each (never with PROF)
+template <class R, bool PROF, int CSG, bool FAR, bool REPL>
 __global__ __launch_bounds__(RTC_BLOCK, (CSG ? 2 : sizeof(R) == 8 ? RTC_WAVES_F64 : RTC_WAVES_F32)) void trace_kernel(rtc::DScene<R> S, rtc::DCamera<R> cam, rtc::DFrame F, R shade_eps, R shade_eps_rel) {
     __shared__ int s_stack[RTC_BVH_STACK * RTC_BLOCK];
     int* stack = s_stack + threadIdx.x;
     const int lane = threadIdx.x & 63;
-    rtc::Counters<PROF, (CSG > 0), FAR, (CSG == 2)> cnt;
+    rtc::Counters<PROF, (CSG > 0), FAR, (CSG == 2), REPL> cnt;
     rtc::zero_counters(cnt);
     const long long t_start = F.cost ? (long long)wall_clock64() : 0;
     bool lane_on;
-    const long long unit = rtc::wave_unit(F, lane_on);
+    int pixel_lane;
+    const long long unit = rtc::wave_unit(F, lane_on, pixel_lane, cnt.rep, cnt.nrep);
     int x, y;
     size_t o;
-    if (unit >= 0 && lane_on && rtc::work_pixel(F, cam.hsize, cam.vsize, unit * 64 + lane, x, y, o)) {
+    if (unit >= 0 && lane_on && rtc::work_pixel(F, cam.hsize, cam.vsize, unit * 64 + pixel_lane, x, y, o)) {
         rtc::Ray<R> ray = rtc::ray_for_pixel(cam, x, y);
-        cnt.c[0] = 1;
         int hit_leaf;
 #ifdef RTC_TIMELINE
         long long tl_start = wall_clock64();
@@ -68,8 +69,11 @@ __global__ __launch_bounds__(RTC_BLOCK, (CSG ? 2 : sizeof(R) == 8 ? RTC_WAVES_F6
 #ifdef RTC_TIMELINE   /* development build only (tools/timeline.py): start/end ticks (100 MHz) instead of the colour */
         c.x = (R)(double)(tl_start & 0xFFFFFFFFFFLL); c.y = (R)(double)(wall_clock64() & 0xFFFFFFFFFFLL); c.z = R(0);
 #endif
-        F.rgb[3 * o] = (double)c.x; F.rgb[3 * o + 1] = (double)c.y; F.rgb[3 * o + 2] = (double)c.z;
-        if (F.hit_id) F.hit_id[o] = hit_leaf;
+        if (cnt.rep == 0) {
+            cnt.c[0] = 1;
+            F.rgb[3 * o] = (double)c.x; F.rgb[3 * o + 1] = (double)c.y; F.rgb[3 * o + 2] = (double)c.z;
+            if (F.hit_id) F.hit_id[o] = hit_leaf;
+        } else cnt.c[2] = cnt.c[3] = 0;               // replicas trace the same camera, reflection and refraction rays: counted once
     }
     if (F.cost && unit >= 0 && lane == 0) {
         long long dt = (long long)wall_clock64() - t_start;
@@ -164,8 +168,10 @@ __global__ __launch_bounds__(1024) void order_kernel(const uint32_t* cost, int32
         total = run;
     }
     __syncthreads();
-    // (Tried: spreading the cheapest workgroups -- sky, a few us each, dispatch-bound at the end of a descending order -- evenly
-    // among the middle ones.  Not faster: every cheap workgroup dispatched earlier delays a dearer one behind it.)
+    // (Tried, not kept: spreading the cheapest workgroups -- sky, a few us each, the last 100 us of a descending order at a third
+    // of the wave slots -- among the middle ones: every cheap workgroup dispatched earlier delays a dearer one behind it; and lists
+    // of four cheap units behind one entry, rendered by one wave in a loop: the loop around the pixel code cost the fp64 kernel
+    // 50 more spilled registers, dragons -2 %, teapot / earth / cover +4 ... +13 %.)
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
         uint32_t c = cost[i];
         unsigned int k = ways[order_bucket(c)];
@@ -352,6 +358,7 @@ struct rtc_scene {
     rtc::DScene<double> d64;
     rtc::DScene<float> d32;
     bool has_jitter = false, has_csg = false, has_csg_stream = false;
+    long long light_cells = 0;      // shadow rays per shaded hit: 1 per point light, usteps x vsteps per area light
     std::mutex ws_mutex;      // guards the workspace list
     std::vector<Workspace*> workspaces;
     int n_cus = 0;
@@ -536,9 +543,10 @@ int validate(const rtc_scene_desc& d) {
 }
 
 // split units dearer than these x (total cost / wave slots) into 4 / 16 waves; 0 = never (development overrides: RTC_SPLIT4, RTC_SPLIT16)
-float g_split4 = [] { const char* e = getenv("RTC_SPLIT4"); return e ? (float)atof(e) : 0.65f; }();     // cost of a 4x4 part / cost of its unit; 0 = never split
+float g_split4 = [] { const char* e = getenv("RTC_SPLIT4"); return e ? (float)atof(e) : 0.5f; }();     // cost of a 4x4 part / cost of its unit; 0 = never split
+const bool g_replicas = [] { const char* e = getenv("RTC_REPLICAS"); return !e || atoi(e) != 0; }();     // RTC_REPLICAS=0: parts leave their spare lanes idle
 float g_split_t = [] { const char* e = getenv("RTC_SPLIT_T"); return e ? (float)atof(e) : 0.0f; }();
-float g_split16 = [] { const char* e = getenv("RTC_SPLIT16"); return e ? (float)atof(e) : 0.5f; }();     // the same for a 2x2 part
+float g_split16 = [] { const char* e = getenv("RTC_SPLIT16"); return e ? (float)atof(e) : 0.35f; }();     // the same for a 2x2 part
 
 int create_impl(const rtc_scene_desc& d, rtc_scene* sc) {
     {
@@ -701,6 +709,7 @@ int create_impl(const rtc_scene_desc& d, rtc_scene* sc) {
     for (int i = 0; i < d.n_materials; i++)
         if (d.mat[10 * (size_t)i + 7] != 0.0 || d.mat[10 * (size_t)i + 8] != 0.0) sc->has_secondary = true;
     for (int i = 0; i < d.n_lights; i++) {
+        sc->light_cells += d.light_type[i] == 1 ? (long long)d.light_steps[3 * i] * d.light_steps[3 * i + 1] : 1;
         if (d.light_type[i] == 1 && d.light_steps[3 * i + 2]) sc->has_jitter = true;
     }
     return 0;
@@ -879,19 +888,22 @@ void launch_trace(const rtc_scene* scene, const rtc_camera* cam, const rtc::DFra
     // a camera farther out than the boxes' padding covers (DScene::far_origin) gets the variants that re-base rays
     const double far_origin = scene->d64.far_origin;
     const bool far_cam = std::fabs(cam->inv_transform[3]) > far_origin || std::fabs(cam->inv_transform[7]) > far_origin || std::fabs(cam->inv_transform[11]) > far_origin;
-#define RTC_LAUNCH_TRACE(R, PROF, CSG, SC) do { \
-    if (far_cam) hipLaunchKernelGGL((trace_kernel<R, PROF, CSG, true>), grid, block, 0, stream, SC, make_camera<R>(*cam), F, (R)eps, (R)eps_rel); \
-    else hipLaunchKernelGGL((trace_kernel<R, PROF, CSG, false>), grid, block, 0, stream, SC, make_camera<R>(*cam), F, (R)eps, (R)eps_rel); } while (0)
+    const bool repl = F.replicas != 0 && !prof;
+#define RTC_LAUNCH_K(R, PROF, CSG, FAR, REPL, SC) \
+    hipLaunchKernelGGL((trace_kernel<R, PROF, CSG, FAR, REPL>), grid, block, 0, stream, SC, make_camera<R>(*cam), F, (R)eps, (R)eps_rel)
 #ifdef RTC_DEV_PLAIN_ONLY   /* development builds (tools/build_variant.sh): only the variants the mesh scenes use -- seconds instead of minutes */
-#define RTC_LAUNCH_CSG(R, PROF, SC) do { (void)csg; hipLaunchKernelGGL((trace_kernel<R, PROF, 0, false>), grid, block, 0, stream, SC, make_camera<R>(*cam), F, (R)eps, (R)eps_rel); } while (0)
+#define RTC_LAUNCH_CSG(R, SC) do { (void)csg; (void)far_cam; if (prof) RTC_LAUNCH_K(R, true, 0, false, false, SC); \
+    else if (repl) RTC_LAUNCH_K(R, false, 0, false, true, SC); else RTC_LAUNCH_K(R, false, 0, false, false, SC); } while (0)
 #else
-#define RTC_LAUNCH_CSG(R, PROF, SC) do { \
-    if (!csg) RTC_LAUNCH_TRACE(R, PROF, 0, SC); else if (!scene->has_csg_stream) RTC_LAUNCH_TRACE(R, PROF, 1, SC); else RTC_LAUNCH_TRACE(R, PROF, 2, SC); } while (0)
+#define RTC_LAUNCH_REPL(R, CSG, FAR, SC) do { if (prof) RTC_LAUNCH_K(R, true, CSG, FAR, false, SC); \
+    else if (repl) RTC_LAUNCH_K(R, false, CSG, FAR, true, SC); else RTC_LAUNCH_K(R, false, CSG, FAR, false, SC); } while (0)
+#define RTC_LAUNCH_FAR(R, CSG, SC) do { if (far_cam) RTC_LAUNCH_REPL(R, CSG, true, SC); else RTC_LAUNCH_REPL(R, CSG, false, SC); } while (0)
+#define RTC_LAUNCH_CSG(R, SC) do { \
+    if (!csg) RTC_LAUNCH_FAR(R, 0, SC); else if (!scene->has_csg_stream) RTC_LAUNCH_FAR(R, 1, SC); else RTC_LAUNCH_FAR(R, 2, SC); } while (0)
 #endif
-    if (precision == 64) { if (prof) RTC_LAUNCH_CSG(double, true, scene->d64); else RTC_LAUNCH_CSG(double, false, scene->d64); }
-    else { if (prof) RTC_LAUNCH_CSG(float, true, scene->d32); else RTC_LAUNCH_CSG(float, false, scene->d32); }
+    if (precision == 64) RTC_LAUNCH_CSG(double, scene->d64); else RTC_LAUNCH_CSG(float, scene->d32);
 #undef RTC_LAUNCH_CSG
-#undef RTC_LAUNCH_TRACE
+#undef RTC_LAUNCH_K
 }
 
 int launch(rtc_scene* scene, const rtc_camera* cam, const rtc_render_opts* opts, int32_t n_tiles, const int32_t* tile_ids_dev,
@@ -909,6 +921,7 @@ int launch(rtc_scene* scene, const rtc_camera* cam, const rtc_render_opts* opts,
     F.n_tiles = n_tiles; F.tile_size = T; F.tiles_x = tiles_x; F.tile_ids = tile_ids_dev;
     F.rgb = rgb_dev; F.hit_id = hit_id_dev; F.rays = reinterpret_cast<unsigned long long*>(rays_dev);
     F.max_depth = depth; F.seed = opts ? opts->seed : 0;
+    F.replicas = 0;
     long long work = (long long)n_tiles * T * T;
     long long blocks = (work + RTC_BLOCK - 1) / RTC_BLOCK;
     if (blocks > 0x7FFFFFFFLL) return fail(RTC_ERR_LIMIT, "too many blocks");
@@ -961,6 +974,8 @@ int launch(rtc_scene* scene, const rtc_camera* cam, const rtc_render_opts* opts,
             long long used = n_entries;
             if (!ws->fb_used_known && ws->fb_used_event && hipEventQuery(ws->fb_used_event) == hipSuccess) ws->fb_used_known = true;
             if (ws->fb_used_known && *ws->fb_used_host >= n_units && *ws->fb_used_host <= n_entries) used = *ws->fb_used_host;
+            // more entries than units = some units are split: their parts' pixels get several lanes each (the REPL kernel variants)
+            if (ws->fb_used_known && used > n_units && !work_dev && scene->light_cells >= 1 && scene->light_cells <= 128 && g_replicas) F.replicas = 1;
             (void)hipGetLastError();       // a not-ready query is not an error
             used = (used + RTC_BLOCK / 64 - 1) / (RTC_BLOCK / 64) * (RTC_BLOCK / 64);
             F.n_entries = (int32_t)used;
@@ -1254,6 +1269,7 @@ int rtc_render_device_noalloc(rtc_scene* scene, const rtc_camera* cam, const rtc
     const bool prof = rays_dev && opts && (opts->flags & RTC_FLAG_COUNT_WORK);
     F.work = prof ? reinterpret_cast<unsigned long long*>(rays_dev + 4) : nullptr;
     F.max_depth = depth; F.seed = opts ? opts->seed : 0;
+    F.replicas = 0;      // this entry point never reads back whether the order holds split units, so their parts leave the spare lanes idle
     F.order = nullptr; F.cost = nullptr;
     F.n_units = (int32_t)n_units; F.n_entries = (int32_t)n_units;
     dim3 grid((unsigned)blocks);

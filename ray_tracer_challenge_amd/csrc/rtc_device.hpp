@@ -161,20 +161,32 @@ struct DFrame {
     int32_t n_units, n_entries;
     const int32_t* order;        // [n_entries], or NULL = units 0, 1, 2, ... whole
     uint32_t* cost;              // [n_units] wall-clock ticks spent on the unit (parts add up; zeroed by the host), or NULL
+    // A part has 16 or 4 pixels for 64 lanes.  With `replicas` set every pixel of a part is traced by 4 (16) adjacent lanes
+    // that do the same thing -- except in the light loop, where they share the shadow rays out among themselves
+    // (shade_ray).  Without it the spare lanes of a part are idle.  The host sets it unless the frame counts work or the
+    // scene's lights have more than 128 cells together.
+    int32_t replicas;
 };
 
-// the unit of this wave (-1 if there is none) and which of its lanes take part
-__device__ __forceinline__ long long wave_unit(const DFrame& F, bool& lane_on) {
+// the unit of this wave (-1 if there is none), which of its lanes take part, the pixel of the 8x8 block each lane has
+// (0..63, row-major) and which replica of that pixel the lane is (rep of nrep: 0 of 1 unless the part is replicated)
+__device__ __forceinline__ long long wave_unit(const DFrame& F, bool& lane_on, int& pixel_lane, int& rep, int& nrep) {
     long long entry = (long long)blockIdx.x * (RTC_BLOCK / 64) + (threadIdx.x >> 6);
     lane_on = true;
+    pixel_lane = threadIdx.x & 63; rep = 0; nrep = 1;
     if (!F.order) return entry < F.n_units ? entry : -1;
     if (entry >= F.n_entries) return -1;
     int e = F.order[entry];
     if (e < 0) return -1;
     int u = e >> 5, part = e & 31;
     if (u >= F.n_units || part > 20) return -1;
-    const int lx = threadIdx.x & 7, ly = (threadIdx.x >> 3) & 7;
-    if (part >= 5) lane_on = (lx >> 1) == ((part - 5) & 3) && (ly >> 1) == ((part - 5) >> 2);
+    const int lane = threadIdx.x & 63, lx = lane & 7, ly = lane >> 3;
+    if (part != 0 && F.replicas) {
+        int bx, by;
+        if (part >= 5) { const int q = part - 5, p = lane >> 4; rep = lane & 15; nrep = 16; bx = (q & 3) * 2 + (p & 1); by = (q >> 2) * 2 + (p >> 1); }
+        else { const int q = part - 1, p = lane >> 2; rep = lane & 3; nrep = 4; bx = (q & 1) * 4 + (p & 3); by = (q >> 1) * 4 + (p >> 2); }
+        pixel_lane = by * 8 + bx;
+    } else if (part >= 5) lane_on = (lx >> 1) == ((part - 5) & 3) && (ly >> 1) == ((part - 5) >> 2);
     else if (part != 0) lane_on = (((ly >> 2) << 1) | (lx >> 2)) == part - 1;
     return u;
 }
@@ -189,10 +201,15 @@ enum { W_NODE = 0, W_TRI = 1, W_LEAF = 2, W_CSG = 3, W_SHADE = 4, W_LIGHT = 5, W
 // FAR = the camera is farther from the scene than the boxes' padding covers: rays are re-based where they enter a tree
 // (traverse_bvh); the host picks it from the camera alone, since every other ray starts on a surface of the scene.
 // STREAM = some CSG root of the scene is evaluated list-free (csg_stream): only those scenes' variants carry that code.
-template <bool PROF, bool CSG = true, bool FAR = false, bool STREAM = false> struct Counters {
+// REPL = the launch order has split parts whose pixels are traced by several lanes each (DFrame::replicas): only those
+// launches' variants carry the replicated light loop (inlined into every variant it cost the fp64 kernel 18 more spilled
+// registers: teapot +9 %, earth +15 % at 1080p, where nothing is split).
+template <bool PROF, bool CSG = true, bool FAR = false, bool STREAM = false, bool REPL = false> struct Counters {
     static constexpr bool kCsg = CSG;
     static constexpr bool kFar = FAR;
     static constexpr bool kStream = CSG && STREAM;
+    static constexpr bool kReplicas = REPL;
+    int rep, nrep;             // this lane is replica `rep` of `nrep` of its pixel (wave_unit); nrep is the same for the whole wave
     unsigned int c[5];         // primary, shadow, reflection, refraction rays traced; shadow rays not traced (light behind the surface)
     unsigned int w[PROF ? W_COUNT : 1];
 #ifdef RTC_LANE_STATS   /* development build (tools/lane_stats.py): every counter counts WAVE-level executions, x 65536 */
@@ -1199,6 +1216,60 @@ __device__ __forceinline__ V3<R> lighting(const DScene<R>& S, V3<R> amb, V3<R> m
     return amb + mean * (R(lit) / R(ls.samples));
 }
 
+// The light loop of a replicated part (DFrame::replicas): the nrep lanes of a pixel hold the same hit.  The shadow rays of
+// all lights -- "items", numbered light by light, cell by cell in count_lit's order -- are dealt out round robin: in round k
+// replica r traces item k * nrep + r, a ballot collects the round's answers, and every replica keeps all of them (128 bits).
+// Then each replica adds the lights up in the reference's order with the lit counts read from the bits: the same
+// arithmetic on the same values as the one-lane loop, so the same colour to the last bit -- in a quarter (a sixteenth)
+// of the dependent tree walks.  A light that cannot contribute is not traced here either (its items count as culled).
+__device__ __forceinline__ int count_bits(unsigned long long b0, unsigned long long b1, int start, int n) {
+    int c = 0;
+    if (start < 64) {
+        const int e = start + n < 64 ? start + n : 64, w = e - start;
+        c += __popcll(b0 & ((w >= 64 ? ~0ull : ((1ull << w) - 1ull)) << start));
+    }
+    if (start + n > 64) {
+        const int s1 = (start > 64 ? start : 64) - 64, w = start + n - 64 - s1;
+        c += __popcll(b1 & ((w >= 64 ? ~0ull : ((1ull << w) - 1ull)) << s1));
+    }
+    return c;
+}
+template <class R, class CNT>
+__device__ __forceinline__ V3<R> light_loop_replicated(const DScene<R>& S, const HitCtx<R>& c, V3<R> pcolor, int* stack, CNT& cnt, uint64_t seed,
+                                                       uint32_t pixel, uint32_t path) {
+    const int nrep = cnt.nrep, rep = cnt.rep, lane = threadIdx.x & 63;
+    int items = 0;
+    for (int l = 0; l < S.n_lights; l++) items += light_shape(S, l).samples;
+    unsigned long long bits0 = 0, bits1 = 0;
+    int l = 0, start_l = 0, samples_l = S.n_lights > 0 ? light_shape(S, 0).samples : 0, known_l = -1;
+    bool matters = false;
+    for (int k0 = 0; k0 < items; k0 += nrep) {
+        const int i = k0 + rep;
+        bool lit = false;
+        if (i < items) {
+            while (i >= start_l + samples_l) { start_l += samples_l; l++; samples_l = light_shape(S, l).samples; }
+            if (l != known_l) { V3<R> amb, mean; matters = light_terms(S, c, pcolor, l, cnt, seed, pixel, path, amb, mean); known_l = l; }
+            if (matters) {
+                const LightShape ls = light_shape(S, l);
+                const int cell = i - start_l;
+                lit = !is_shadowed(S, light_sample<R>(S, l, ls, cell % ls.usteps, cell / ls.usteps, seed, pixel, path, 0), c.over_point, stack, cnt);
+            } else cnt.c[4]++;
+        }
+        const unsigned long long round = (__builtin_amdgcn_ballot_w64(lit) >> (lane & ~(nrep - 1))) & ((1ull << nrep) - 1ull);
+        if (k0 < 64) bits0 |= round << k0; else bits1 |= round << (k0 - 64);        // nrep divides 64: a round never straddles
+    }
+    V3<R> surface = mk<R>(0, 0, 0);
+    int start = 0;
+    for (int m = 0; m < S.n_lights; m++) {
+        V3<R> amb, mean;
+        const bool contributes = light_terms(S, c, pcolor, m, cnt, seed, pixel, path, amb, mean);
+        const int samples = light_shape(S, m).samples;
+        surface = surface + lighting(S, amb, mean, m, contributes ? count_bits(bits0, bits1, start, samples) : 0);
+        start += samples;
+    }
+    return surface;
+}
+
 // n1 / n2 from what the container pass found: X = the hit leaf (in `containers` iff x_odd, entered
 // last at x_last), Y = the other odd-parity leaf entered last (at y_last), or none
 template <class R>
@@ -1291,6 +1362,7 @@ __device__ __forceinline__ V3<R> shade_ray(const DScene<R>& S, const Ray<R>& ray
         Secondary<R> sec = secondary_rays(S, c, remaining, n1, n2);
         if (!emit(sec.refl, c.over_point, c.reflectv, sec.w_refl, sec.refr, c.under_point, sec.refr_dir, sec.w_refr)) return surface;
         V3<R> pcolor = surface_color<R, CNT::kCsg>(S, c.material, c.leaf, c.over_point);
+        if (CNT::kReplicas && cnt.nrep > 1) return light_loop_replicated(S, c, pcolor, stack, cnt, seed, pixel, path);
         for (int l = 0; l < S.n_lights; l++) {
             V3<R> amb, mean;
             const bool matters = light_terms(S, c, pcolor, l, cnt, seed, pixel, path, amb, mean);
@@ -1367,8 +1439,8 @@ template <class R> __device__ __forceinline__ Ray<R> ray_for_pixel(const DCamera
 }
 
 // block-level reduction of the ray / work counters, then a few atomics per block
-template <bool PROF, bool CSG, bool FAR, bool STREAM>
-__device__ __forceinline__ void flush_counters(Counters<PROF, CSG, FAR, STREAM>& cnt, const DFrame& F, unsigned int* red /* LDS, >= 5 * RTC_BLOCK/64 */) {
+template <bool PROF, bool CSG, bool FAR, bool STREAM, bool REPL>
+__device__ __forceinline__ void flush_counters(Counters<PROF, CSG, FAR, STREAM, REPL>& cnt, const DFrame& F, unsigned int* red /* LDS, >= 5 * RTC_BLOCK/64 */) {
     if (F.rays) {
         __syncthreads();
         for (int k = 0; k < 5; k++) {
@@ -1391,7 +1463,8 @@ __device__ __forceinline__ void flush_counters(Counters<PROF, CSG, FAR, STREAM>&
         }
     }
 }
-template <bool PROF, bool CSG, bool FAR, bool STREAM> __device__ __forceinline__ void zero_counters(Counters<PROF, CSG, FAR, STREAM>& cnt) {
+template <bool PROF, bool CSG, bool FAR, bool STREAM, bool REPL> __device__ __forceinline__ void zero_counters(Counters<PROF, CSG, FAR, STREAM, REPL>& cnt) {
+    cnt.rep = 0; cnt.nrep = 1;
     for (int k = 0; k < 5; k++) cnt.c[k] = 0;
     for (int k = 0; k < (PROF ? W_COUNT : 1); k++) cnt.w[k] = 0;
 }

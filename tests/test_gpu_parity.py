@@ -279,10 +279,14 @@ def test_nested_and_blended_patterns_and_nested_csg(oracle_cls):
     assert frac_off_by_more_than_one(got32, want) <= 0.02
 
 
-@pytest.mark.parametrize("name,size", [("cover", None), ("dragons", (480, 192)), ("teapot", None)])
+@pytest.mark.parametrize("name,size", [("cover", None), ("dragons", (480, 192)), ("teapot", None), ("shadow_glamour_shot", (240, 96)),
+                                       ("shadow_glamour_shot_nojitter", (240, 96)), ("csg_test", (192, 192)), ("perturbed", (160, 100))])
 def test_launch_order_feedback_changes_nothing(name, size, scenes):
     """Frames after the first launch the dearest 8x8 blocks first (costs recorded by the previous frame on the
-    same scene handle); any launch order must give bit-identical images, ids and ray counts."""
+    same scene handle), and from the third frame on with the dearest blocks split into 4x4 or 2x2 parts whose pixels
+    are each traced by 4 or 16 lanes that share the shadow rays out among themselves (point lights: one light each;
+    the area light's 100 cells: 25 or 7 rounds): any launch order and any split must give bit-identical images, ids
+    and ray counts."""
     cam, world, sc = scenes(name)
     if size:
         cam = cam.resized(*size)
