@@ -213,7 +213,7 @@ def main():
                                "shadow_queries_answered_without_a_ray": rays[4] // args.steps},
             "reference_equivalent_mrays_per_s": round((total_rays + rays[4]) / dt / 1e6, 3),
             "ms_per_frame": round(dt / args.steps * 1e3, 4),
-            "launch_order": {"policy": "dearest 8x8 blocks first, from the wave costs the first two frames of a view record",
+            "launch_order": {"policy": "dearest 8x8 blocks first, from the wave costs the first two frames of a view record; the dearest blocks split into 4x4 / 2x2 parts whose pixels are traced by 4 / 16 lanes sharing the shadow rays (DESIGN.md 4.1)",
                              "ms_per_frame_plain_tile_order": None if plain is None else round(plain, 4)},
             "fp32": {"value": round(sum(rays32[:4]) / dt32 / 1e6, 3), "unit": "Mrays/s", "ms_per_frame": round(dt32 / args.steps * 1e3, 4),
                      "kernel_ms": round(kms32, 4), "repeats": len(reps32),

@@ -17,7 +17,6 @@ marks = []
 for it in range(n):
     with _ffi.Scene(cs) as sc:
         sc.render(cam, precision="fp64", want_ids=True)
-        sc.render(cam, precision="fp32", wavefront=True)
         sc.render_ppm(cam)
         sc.render_tiles(cam, np.arange(0, 40, 3, dtype=np.int32), want_ids=True)
         sc.update_triangles(cs.arrays["tri_geom"], cs.arrays["tri_norm"], refit=True)

@@ -28,7 +28,7 @@ for lib in libs:
         cam, cs = scenes[name]
         with _ffi.Scene(cs) as sc:
             row = []
-            forms = [("fb", {}), ("nofb", {"feedback": False}), ("lv", {"wavefront": True})] + ([("wf", {"wavefront": True})] if os.environ.get("QB_WF") else [])
+            forms = [("fb", {}), ("nofb", {"feedback": False})]
             for prec, mega in [(p_, f_) for p_ in ("fp64", "fp32") for f_ in forms]:
                 ms = []
                 for it in range(6):

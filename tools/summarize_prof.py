@@ -13,11 +13,11 @@ c = sqlite3.connect(os.path.join(src, "kt", "kt_results.db"))
 lines.append("%-110s %6s %14s %12s %7s" % ("kernel", "calls", "total_us", "avg_us", "%"))
 for name, calls, total, avg, pct in c.execute("select name,total_calls,total_duration,average,percentage from top_kernels"):
     lines.append("%-110s %6d %14.3f %12.3f %7.2f" % (name[:110], calls, total, avg, pct))
-rows = [(e - b) / 1000.0 for b, e in c.execute("select start, end from kernels where name like '%trace_kernel<double, false%' order by start")]
+rows = [(e - b) / 1000.0 for b, e in c.execute("select start, end from kernels where name like '%trace_kernel<double, false, 0, false, true>%' order by start")]
 if rows:
     import statistics
-    lines += ["", "trace_kernel<double, false, *> per launch, in launch order (us): the first two frames of a view run in plain tile order and",
-              "record wave costs, the last launches are bench.py's plain-order comparison; the median is the steady state bench.py times:",
+    lines += ["", "trace_kernel<double, false, 0, false, true> (the steady-state variant: launch order with split units) per launch, in launch order (us);",
+              "the first frames of a view -- cost measurement, plain order -- run trace_kernel<double, false, 0, false, false>, listed above:",
               " ".join("%.0f" % r for r in rows[:40]) + (" ... (%d launches)" % len(rows) if len(rows) > 40 else ""),
               "median %.1f us, mean %.1f us, min %.1f us, max %.1f us over %d launches" % (
                   statistics.median(rows), statistics.mean(rows), min(rows), max(rows), len(rows))]
@@ -25,7 +25,7 @@ with open(os.path.join(src, "bench_under_rocprof.json")) as f:
     lines += ["", "bench.py JSON line of the same run:", f.read().strip()]
 open(os.path.join("profiles", tag + "_kernel_trace_stats.txt"), "w").write("\n".join(lines) + "\n")
 
-out = ["rocprofv3 --pmc passes (one counter group per run) over python3 bench.py --steps 3 --warmup 1 --min-seconds 0   (%s)" % tag,
+out = ["rocprofv3 --pmc passes (one counter group per run) over python3 bench.py --steps 6 --warmup 4 --min-seconds 0   (%s)" % tag,
        "FETCH_SIZE / WRITE_SIZE are in KiB as rocprofv3 reports them; per MI355X_MICROARCH.md FETCH_SIZE counts 64 B per",
        "128-B request for wide coalesced reads (x2 correction); this kernel's reads are scattered 8..16-B loads, for which",
        "the guide calls the absolute value uncalibrated, so both raw and x2 are given.", ""]
@@ -40,7 +40,10 @@ for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_mem", "pmc_cache"):
         short = k[k.index("trace_kernel"):k.index("(rtc")]
         out.append("%-28s %-22s n=%-3d avg=%.1f" % (short, cn, n, avg))
         traffic.setdefault(short, {})[cn] = avg
-k64 = next((v for k, v in traffic.items() if k.startswith("trace_kernel<double, false")), {})
+# the steady-state kernel of the dragons frame is the variant for orders with split units (..., true>); the first frames of a
+# view (cost measurement, and the one before the host knows the order holds splits) run the plain variant
+k64 = next((v for k, v in traffic.items() if k.startswith("trace_kernel<double, false") and k.rstrip().endswith("true>")), None) or \
+      next((v for k, v in traffic.items() if k.startswith("trace_kernel<double, false")), {})
 if "FETCH_SIZE" in k64 and "WRITE_SIZE" in k64:
     js = {"source": "profiles/%s_pmc.txt" % tag,
           "fetch_bytes_raw_fp64": k64["FETCH_SIZE"] * 1024, "write_bytes_fp64": k64["WRITE_SIZE"] * 1024,
