@@ -45,8 +45,12 @@ int fail(int code, const char* fmt, ...) {
 // ---------------------------------------------------------------------------------------------
 // CSG: 0 = the scene has no CSG object and no perturbed pattern, 1 = it has, 2 = and some CSG root is evaluated list-free
 // REPL: the pixels of split parts are traced by 4 or 16 lanes each (never with PROF)
-template <class R, bool PROF, int CSG, bool FAR, bool REPL>
-__global__ __launch_bounds__(RTC_BLOCK, (CSG ? 2 : sizeof(R) == 8 ? RTC_WAVES_F64 : RTC_WAVES_F32)) void trace_kernel(rtc::DScene<R> S, rtc::DCamera<R> cam, rtc::DFrame F, R shade_eps, R shade_eps_rel) {
+// WAVES: resident waves per SIMD the register budget is cut for (512 / WAVES registers per lane).  fp64 is built for 3 (168
+// registers, ~100 spilled) and, without CSG, for 2 as well (256 registers, none spilled): which is faster depends on the scene
+// -- tree walks want the waves, fp64 pattern arithmetic wants the registers -- and launch() times both for every view.
+#define RTC_WAVES_OF(R, CSG) ((CSG) ? 2 : sizeof(R) == 8 ? RTC_WAVES_F64 : RTC_WAVES_F32)
+template <class R, bool PROF, int CSG, bool FAR, bool REPL, int WAVES>
+__global__ __launch_bounds__(RTC_BLOCK, WAVES) void trace_kernel(rtc::DScene<R> S, rtc::DCamera<R> cam, rtc::DFrame F, R shade_eps, R shade_eps_rel) {
     __shared__ int s_stack[RTC_BVH_STACK * RTC_BLOCK];
     int* stack = s_stack + threadIdx.x;
     const int lane = threadIdx.x & 63;
@@ -338,6 +342,12 @@ struct Workspace {
     long long fb_units = 0; int fb_cur = 0; bool fb_valid = false;
     int32_t* fb_used_dev = nullptr; int32_t* fb_used_host = nullptr;   // entries the current order really has (host copy: pinned)
     hipEvent_t fb_used_event = nullptr; bool fb_used_known = false;
+    // fp64 without CSG exists for 3 and for 2 waves per SIMD (trace_kernel's WAVES): once a view's order has settled, four
+    // frames are timed -- 3, 2, 3, 2 waves; events around the launch, read when they have completed -- and the budget with the
+    // faster best frame is kept for the view (the first launch of a variant is slower than its later ones)
+    hipEvent_t tune_ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    int tune_stage = 0;          // 0: order not settled yet, 1..4: the next frame is timed (odd: 3 waves, even: 2), 5: waiting for the events, 6: decided
+    bool tune_two_waves = false;
     // what the current order was measured on, and how many frames of it have been sorted: the order is rebuilt
     // after the first two frames of a view (the second one measured under the new order) and then kept
     FbKey fb_key{}; int fb_age = 0;
@@ -346,6 +356,7 @@ struct Workspace {
         if (fb_used_host) (void)hipHostFree(fb_used_host);
         if (fb_used_event) (void)hipEventDestroy(fb_used_event);
         if (done) (void)hipEventDestroy(done);
+        for (hipEvent_t e : tune_ev) if (e) (void)hipEventDestroy(e);
     }
 };
 
@@ -545,6 +556,7 @@ int validate(const rtc_scene_desc& d) {
 // split units dearer than these x (total cost / wave slots) into 4 / 16 waves; 0 = never (development overrides: RTC_SPLIT4, RTC_SPLIT16)
 float g_split4 = [] { const char* e = getenv("RTC_SPLIT4"); return e ? (float)atof(e) : 0.5f; }();     // cost of a 4x4 part / cost of its unit; 0 = never split
 const bool g_replicas = [] { const char* e = getenv("RTC_REPLICAS"); return !e || atoi(e) != 0; }();     // RTC_REPLICAS=0: parts leave their spare lanes idle
+const bool g_tune_waves = [] { const char* e = getenv("RTC_TUNE_WAVES"); return !e || atoi(e) != 0; }();   // RTC_TUNE_WAVES=0: fp64 always at 3 waves per SIMD
 float g_split_t = [] { const char* e = getenv("RTC_SPLIT_T"); return e ? (float)atof(e) : 0.0f; }();
 float g_split16 = [] { const char* e = getenv("RTC_SPLIT16"); return e ? (float)atof(e) : 0.35f; }();     // the same for a 2x2 part
 
@@ -882,15 +894,18 @@ struct WorkspaceLease {
 
 // the trace kernel variant for (precision, counting, CSG / perturbed patterns) on `grid` workgroups
 void launch_trace(const rtc_scene* scene, const rtc_camera* cam, const rtc::DFrame& F, dim3 grid, int precision, bool prof, double eps, double eps_rel,
-                  hipStream_t stream) {
+                  hipStream_t stream, bool two_waves = false) {
     const dim3 block(RTC_BLOCK);
     const bool csg = scene->has_csg;
     // a camera farther out than the boxes' padding covers (DScene::far_origin) gets the variants that re-base rays
     const double far_origin = scene->d64.far_origin;
     const bool far_cam = std::fabs(cam->inv_transform[3]) > far_origin || std::fabs(cam->inv_transform[7]) > far_origin || std::fabs(cam->inv_transform[11]) > far_origin;
     const bool repl = F.replicas != 0 && !prof;
-#define RTC_LAUNCH_K(R, PROF, CSG, FAR, REPL, SC) \
-    hipLaunchKernelGGL((trace_kernel<R, PROF, CSG, FAR, REPL>), grid, block, 0, stream, SC, make_camera<R>(*cam), F, (R)eps, (R)eps_rel)
+#define RTC_LAUNCH_W(R, PROF, CSG, FAR, REPL, W, SC) \
+    hipLaunchKernelGGL((trace_kernel<R, PROF, CSG, FAR, REPL, W>), grid, block, 0, stream, SC, make_camera<R>(*cam), F, (R)eps, (R)eps_rel)
+#define RTC_LAUNCH_K(R, PROF, CSG, FAR, REPL, SC) do { \
+    if (sizeof(R) == 8 && !(PROF) && (CSG) == 0 && two_waves) RTC_LAUNCH_W(R, PROF, CSG, FAR, REPL, ((sizeof(R) == 8 && !(PROF) && (CSG) == 0) ? 2 : RTC_WAVES_OF(R, CSG)), SC); \
+    else RTC_LAUNCH_W(R, PROF, CSG, FAR, REPL, RTC_WAVES_OF(R, CSG), SC); } while (0)
 #ifdef RTC_DEV_PLAIN_ONLY   /* development builds (tools/build_variant.sh): only the variants the mesh scenes use -- seconds instead of minutes */
 #define RTC_LAUNCH_CSG(R, SC) do { (void)csg; (void)far_cam; if (prof) RTC_LAUNCH_K(R, true, 0, false, false, SC); \
     else if (repl) RTC_LAUNCH_K(R, false, 0, false, true, SC); else RTC_LAUNCH_K(R, false, 0, false, false, SC); } while (0)
@@ -904,6 +919,7 @@ void launch_trace(const rtc_scene* scene, const rtc_camera* cam, const rtc::DFra
     if (precision == 64) RTC_LAUNCH_CSG(double, scene->d64); else RTC_LAUNCH_CSG(float, scene->d32);
 #undef RTC_LAUNCH_CSG
 #undef RTC_LAUNCH_K
+#undef RTC_LAUNCH_W
 }
 
 int launch(rtc_scene* scene, const rtc_camera* cam, const rtc_render_opts* opts, int32_t n_tiles, const int32_t* tile_ids_dev,
@@ -962,7 +978,7 @@ int launch(rtc_scene* scene, const rtc_camera* cam, const rtc_render_opts* opts,
             ws->fb_mem.bytes = (size_t)n_units * 4 + (size_t)n_entries * 8;
             ws->fb_units = n_units;
         }
-        if (memcmp(&key, &ws->fb_key, sizeof(key)) != 0) { ws->fb_key = key; ws->fb_age = 0; }
+        if (memcmp(&key, &ws->fb_key, sizeof(key)) != 0) { ws->fb_key = key; ws->fb_age = 0; ws->tune_stage = 0; ws->tune_two_waves = false; }
         resort = ws->fb_age < 2;
         ws->fb_age++;
         if (resort) {
@@ -982,7 +998,29 @@ int launch(rtc_scene* scene, const rtc_camera* cam, const rtc_render_opts* opts,
             grid = dim3((unsigned)(used / (RTC_BLOCK / 64)));
         }
     }
-    launch_trace(scene, cam, F, grid, precision, work_dev != nullptr, eps, eps_rel, stream);
+    // which of the two fp64 register budgets for this view (see Workspace::tune_ev)
+    bool two_waves = false;
+    int timing = -1;
+    if (ws && g_tune_waves && precision == 64 && !csg && !work_dev) {
+        if (ws->tune_stage == 0 && !resort && ws->fb_valid && ws->fb_used_known) ws->tune_stage = 1;
+        if (ws->tune_stage >= 1 && ws->tune_stage <= 4) {
+            if (!ws->tune_ev[0]) for (hipEvent_t& e : ws->tune_ev) HIP_TRY(hipEventCreate(&e));
+            timing = 2 * (ws->tune_stage - 1);
+            two_waves = (ws->tune_stage & 1) == 0;
+            ws->tune_stage++;
+        } else if (ws->tune_stage == 5 && hipEventQuery(ws->tune_ev[7]) == hipSuccess) {
+            float ms[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            bool ok = true;
+            for (int k = 0; k < 4; k++) ok = ok && hipEventElapsedTime(&ms[k], ws->tune_ev[2 * k], ws->tune_ev[2 * k + 1]) == hipSuccess;
+            ws->tune_two_waves = ok && std::min(ms[1], ms[3]) < 0.95f * std::min(ms[0], ms[2]);       // the wider budget has to win by 5 %
+            ws->tune_stage = 6;
+        }
+        (void)hipGetLastError();       // a not-ready query is not an error
+        if (ws->tune_stage == 6) two_waves = ws->tune_two_waves;
+    }
+    if (timing >= 0) HIP_TRY(hipEventRecord(ws->tune_ev[timing], stream));
+    launch_trace(scene, cam, F, grid, precision, work_dev != nullptr, eps, eps_rel, stream, two_waves);
+    if (timing >= 0) HIP_TRY(hipEventRecord(ws->tune_ev[timing + 1], stream));
     HIP_TRY(hipGetLastError());
     if (feedback && resort) {
         // this frame's costs -> the order the next frame of this view launches in (other buffer: the

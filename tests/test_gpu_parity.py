@@ -285,15 +285,15 @@ def test_launch_order_feedback_changes_nothing(name, size, scenes):
     """Frames after the first launch the dearest 8x8 blocks first (costs recorded by the previous frame on the
     same scene handle), and from the third frame on with the dearest blocks split into 4x4 or 2x2 parts whose pixels
     are each traced by 4 or 16 lanes that share the shadow rays out among themselves (point lights: one light each;
-    the area light's 100 cells: 25 or 7 rounds): any launch order and any split must give bit-identical images, ids
-    and ray counts."""
+    the area light's 100 cells: 25 or 7 rounds), and fp64 frames are timed at two register budgets (kernel variants for 3
+    and 2 waves per SIMD): any launch order, any split and either variant must give bit-identical images, ids and ray counts."""
     cam, world, sc = scenes(name)
     if size:
         cam = cam.resized(*size)
     for prec in ("fp64", "fp32"):
         s0 = {}
         plain, ids0 = sc.render(cam, precision=prec, want_ids=True, stats=s0, feedback=False)
-        for frame in range(4):          # natural order, first sorted order, re-sorted order, kept order
+        for frame in range(10):         # natural order, sorted order, split order, replicas, then fp64 at 3 / 2 / 3 / 2 waves per SIMD, the kept one
             st = {}
             got, ids = sc.render(cam, precision=prec, want_ids=True, stats=st)
             np.testing.assert_array_equal(got, plain)
