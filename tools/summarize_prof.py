@@ -17,7 +17,7 @@ rows = [(e - b) / 1000.0 for b, e in c.execute("select start, end from kernels w
 if rows:
     import statistics
     lines += ["", "trace_kernel<double, false, 0, false, true, 3> (the steady-state variant: launch order with split units, 3 waves per SIMD) per launch, in launch order (us);",
-              "the first frames of a view -- cost measurement, plain order -- run trace_kernel<double, false, 0, false, false>, listed above:",
+              "the first frames of a view -- cost measurement, plain order -- run trace_kernel<double, false, 0, false, false, 3>, and two timed frames the 2-wave variant, listed above:",
               " ".join("%.0f" % r for r in rows[:40]) + (" ... (%d launches)" % len(rows) if len(rows) > 40 else ""),
               "median %.1f us, mean %.1f us, min %.1f us, max %.1f us over %d launches" % (
                   statistics.median(rows), statistics.mean(rows), min(rows), max(rows), len(rows))]
