@@ -177,6 +177,10 @@ def main(which):
         # this repository's own scene (scenes/src/perturbed.yml) through the reference's PerturbedPattern, with
         # oracle/_stubs/noise.py standing in for the absent PyPI `noise`: pins the pattern's wiring, NOT the noise function
         "perturbed": lambda: make("perturbed", os.path.join(ROOT, "scenes", "src", "perturbed.yml"), ROOT, None, "all"),
+        # this repository's own pattern scene (scenes/src/patterns.yml) through the reference's pattern classes
+        "patterns": lambda: make("patterns", os.path.join(ROOT, "scenes", "src", "patterns.yml"), ROOT, None, "all"),
+        # and its UV-map scene (scenes/src/uvmaps.yml): maps with pattern transforms, on shapes other than their namesakes
+        "uvmaps": lambda: make("uvmaps", os.path.join(ROOT, "scenes", "src", "uvmaps.yml"), REF, None, "all"),
     }
 
     def skybox():

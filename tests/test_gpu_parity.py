@@ -21,7 +21,9 @@ CASES = [("cover", None, 1), ("csg_test", (192, 192), 1), ("group", None, 1), ("
          ("checkered_plane", (160, 160), 1), ("checkered_cylinder", (160, 160), 1), ("align_check_plane", (160, 160), 1),
          ("checkered_cube", (320, 160), 1), ("earth", (320, 160), 1), ("skybox", (320, 160), 1),
          ("shadow_glamour_shot_nojitter", (240, 96), 1), ("teapot", None, 3), ("dragons", (480, 192), 4),
-         ("perturbed", (320, 200), 1)]          # perturbed patterns: noise restated from the published algorithm, parity unpinned
+         ("perturbed", (320, 200), 1),          # perturbed patterns: noise restated from the published algorithm, parity unpinned
+         ("patterns", None, 1),                 # every solid / composite pattern no reference scene uses (reference-rendered fixture)
+         ("uvmaps", None, 1)]                   # UV maps with pattern transforms, on other shapes than their namesakes (likewise)
 GOLDEN = [c[0] for c in CASES]
 
 

@@ -10,7 +10,14 @@ SCENES = ["cover", "csg_test", "group", "checkered_sphere", "checkered_plane", "
           "align_check_plane", "checkered_cube", "earth", "skybox", "shadow_glamour_shot_nojitter", "teapot", "dragons",
           # the reference's PerturbedPattern code with oracle/_stubs/noise.py standing in for the absent PyPI `noise`:
           # pins which point is perturbed and how, not the noise function (parity unpinned)
-          "perturbed"]
+          "perturbed",
+          # this repository's own pattern scene (scenes/src/patterns.yml) rendered by the reference: stripe, gradient, rings,
+          # radial gradient, 3-D checkers, blended, nested, a cylinder map with cap and body patterns of their own, through
+          # group and CSG transforms, in reflection and refraction -- pattern code no scene file of the reference exercises
+          "patterns",
+          # and its UV-map scene (scenes/src/uvmaps.yml), also rendered by the reference: every map with a pattern transform of
+          # its own and on shapes other than its namesake, image / checkers / align-check UV patterns, a cube map on a sphere
+          "uvmaps"]
 
 
 @pytest.mark.parametrize("name", SCENES)

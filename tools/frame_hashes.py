@@ -18,7 +18,7 @@ CASES = [("cover", None), ("csg_test", (192, 192)), ("group", None), ("checkered
          ("checkered_plane", (160, 160)), ("checkered_cylinder", (160, 160)), ("align_check_plane", (160, 160)),
          ("checkered_cube", (320, 160)), ("earth", (320, 160)), ("skybox", (320, 160)),
          ("shadow_glamour_shot_nojitter", (240, 96)), ("shadow_glamour_shot", (240, 96)), ("teapot", None),
-         ("dragons", (480, 192)), ("perturbed", (320, 200)),
+         ("dragons", (480, 192)), ("perturbed", (320, 200)), ("patterns", None), ("uvmaps", None),
          ("dragons", (1920, 1080)), ("cover", (1920, 1080)), ("teapot", (1920, 1080)), ("csg_test", (1024, 1024)),
          ("shadow_glamour_shot", (1200, 480)), ("earth", (1920, 1080))]
 

@@ -62,6 +62,12 @@ def main(which=()):
     if not which or "perturbed" in which:
         pack("perturbed", os.path.join(OUT, "src", "perturbed.yml"), OUT,
              {"source": "scenes/src/perturbed.yml (this repository)", "note": "noise = restated pnoise3, parity unpinned"})
+    # another: the solid patterns and composites no scene file of the reference uses, pinned by a reference-rendered fixture
+    if not which or "patterns" in which:
+        pack("patterns", os.path.join(OUT, "src", "patterns.yml"), OUT, {"source": "scenes/src/patterns.yml (this repository)"})
+    if not which or "uvmaps" in which:
+        pack("uvmaps", os.path.join(OUT, "src", "uvmaps.yml"), REF,
+             {"source": "scenes/src/uvmaps.yml (this repository)", "divergence": "CubeMapPattern transform = identity (reference raises TypeError)"})
     if which and "reference" not in which:
         return
     tm = os.path.join(REF, "texture_mapping")
