@@ -156,6 +156,55 @@ def make_jitter(size=(150, 60), seeds=(0, 1, 2, 3, 4, 5, 6, 7)):
         len(seeds), dt, means.std(axis=0, ddof=1).max(), 1 / 255.0), flush=True)
 
 
+def _ref_pixel_plain(xy):
+    R, S = _G["mods"]["renderer"], _G["mods"]["shapes"]
+    r = R.ray_for_pixel(_G["cam"], xy[0], xy[1])
+    h = S.hit(R.intersect_world(_G["world"], r))
+    return np.asarray(R.color_at(_G["world"], r), dtype=np.float64), (np.inf if h is None else float(h.t))
+
+
+FUZZ_SEEDS = list(range(40)) + [110, 129, 215, 1595, 2004, 2267, 2393]
+
+
+FUZZ_KINDS = {"world": ("random_world", FUZZ_SEEDS), "csg": ("random_csg_world", list(range(16))), "mesh": ("random_mesh_world", list(range(8)))}
+
+
+def make_fuzz(procs=8):
+    """The random worlds of tests/test_gpu_fuzz.py -- general worlds, nested-CSG worlds, tessellated-mesh worlds -- built,
+    same seeds, same draws, out of the REFERENCE's own classes (test_gpu_fuzz.bind) and rendered whole by the reference:
+    colour and primary hit distance of every pixel of every world.  Pins the oracle (and through it the kernel) on what only those worlds hold: every primitive under rotate / scale /
+    shear chains, groups, CSG, glass of mixed refractive indices inside glass (the n1 / n2 walk), objects that cast no shadow,
+    pattern composites on all of them, point and (unjittered) area lights.  PerturbedPattern goes through
+    oracle/_stubs/noise.py, as in the `perturbed` fixture."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import test_gpu_fuzz as F
+    mods = rh.import_reference()
+    out, meta = {}, {"kinds": {}, "remaining": 5, "procs": procs,
+                     "made_by": "oracle/make_golden.py make_fuzz: the world generators of tests/test_gpu_fuzz.py bound to the reference's classes, "
+                                "reference color_at / hit(intersect_world) per pixel, numpy %s" % np.__version__}
+    t0 = time.time()
+    for kind, (fn, seeds) in FUZZ_KINDS.items():
+        rgb, ts = [], []
+        for seed in seeds:
+            F.bind(mods)
+            try:
+                cam, world = getattr(F, fn)(seed)[:2]
+            finally:
+                F.bind(None)
+            xs, ys = np.meshgrid(np.arange(cam.hsize), np.arange(cam.vsize), indexing="ij")
+            _G.update(mods=mods, cam=cam, world=world)
+            with mp.get_context("fork").Pool(procs) as pool:
+                res = pool.map(_ref_pixel_plain, list(zip(xs.ravel().tolist(), ys.ravel().tolist())), chunksize=48)
+            rgb.append(np.array([r[0] for r in res]).reshape(cam.hsize, cam.vsize, 3))
+            ts.append(np.array([r[1] for r in res]).reshape(cam.hsize, cam.vsize))
+            print("fuzz %s %4d: %.1f s so far" % (kind, seed, time.time() - t0), flush=True)
+        out["rgb_" + kind], out["hit_t_" + kind] = np.array(rgb), np.array(ts)
+        meta["kinds"][kind] = {"generator": fn, "seeds": list(seeds), "hsize": int(cam.hsize), "vsize": int(cam.vsize)}
+    meta["reference_seconds"] = round(time.time() - t0, 1)
+    np.savez_compressed(os.path.join(GOLD, "fuzz_worlds.npz"), meta=np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8), **out)
+    print("fuzz_worlds: %d worlds, %.1f s of the reference" % (sum(len(v[1]) for v in FUZZ_KINDS.values()), time.time() - t0), flush=True)
+
+
 def main(which):
     from make_scene_packs import synthetic_faces
     tm = "texture_mapping"
@@ -204,6 +253,7 @@ def main(which):
         make("dragons", "bounding_box_images/bounding_boxes.yml", objs_cwd, (480, 192), (px, py), procs=6)
     jobs["dragons"] = dragons
     jobs["shadow_glamour_shot_jitter"] = make_jitter
+    jobs["fuzz_worlds"] = make_fuzz
 
     for name in (which or list(jobs)):
         jobs[name]()

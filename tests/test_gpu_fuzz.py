@@ -27,7 +27,30 @@ from ray_tracer_challenge_amd.vector import point, vector
 pytestmark = pytest.mark.gpu
 
 HSIZE, VSIZE = 64, 48
+
+
+def bind(mods=None):
+    """Which constructors the world generators below use: this package's (default), or -- `mods` = the dict
+    oracle/ref_harness.import_reference() returns -- the reference's own classes and functions, which have the same names and
+    signatures.  oracle/make_golden.py builds the SAME random worlds (same seeds, same draws) out of the reference's classes
+    that way and renders them with the reference: tests/golden/fuzz_worlds.npz."""
+    g = globals()
+    if mods is None:
+        import ray_tracer_challenge_amd.canvas as c, ray_tracer_challenge_amd.matrix as m, ray_tracer_challenge_amd.renderer as r
+        import ray_tracer_challenge_amd.shapes as sh, ray_tracer_challenge_amd.vector as v
+    else:
+        c, m, r, sh, v = mods["canvas"], mods["matrix"], mods["renderer"], mods["shapes"], mods["vector"]
+    g["S"], g["color"], g["point"], g["vector"] = sh, c.color, v.point, v.vector
+    for name in ("rotation_x", "rotation_y", "rotation_z", "scaling", "shearing", "translation"):
+        g[name] = getattr(m, name)
+    for name in ("AreaLight", "Camera", "World", "point_light", "view_transform"):
+        g[name] = getattr(r, name)
+
 _SPREAD = [2.5]          # how far from the origin objects are scattered (smaller for worlds of few objects, so that they are in view)
+
+
+def _identity():
+    return translation(0, 0, 0)          # (the reference's shapes have no default for a missing transform)
 
 
 def _rgb(rng, lo=0.05, hi=1.0):
@@ -76,8 +99,8 @@ def _pattern(rng, depth=0):
     if r < 0.84:
         return S.TextureMapPattern(_uv_pattern(rng), [S.PlaneUVMap, S.SphereUVMap][rng.integers(2)], _small_transform(rng))
     if r < 0.92:
-        return S.CylinderMapPattern(_uv_pattern(rng), _uv_pattern(rng), transform=_small_transform(rng))
-    return S.CubeMapPattern(*[_uv_pattern(rng) for _ in range(6)], transform=_small_transform(rng))
+        return S.CylinderMapPattern(_uv_pattern(rng), _uv_pattern(rng), S.CylinderUVMap, _small_transform(rng))
+    return S.CubeMapPattern(*[_uv_pattern(rng) for _ in range(6)], S.CubeUVMap, _small_transform(rng))
 
 
 def _material(rng):
@@ -238,6 +261,29 @@ def test_fp32_gate_over_random_worlds(oracle_cls):
     assert far_beyond <= set(FP32_BEYOND_GATE), "worlds newly beyond twice the fp32 gate: %s" % sorted(far_beyond - set(FP32_BEYOND_GATE))
 
 
+def _fuzz_golden():
+    import test_oracle_fuzz_golden as G
+    return G
+
+
+@pytest.mark.parametrize("kind,i", _fuzz_golden().WORLDS)
+def test_random_world_matches_the_reference(kind, i, oracle_cls):
+    """The kernel against the REFERENCE's own frames of these worlds (tests/golden/fuzz_worlds.npz: the same worlds built out of
+    the reference's classes and rendered by it -- general, nested-CSG and mesh worlds; tests/test_oracle_fuzz_golden.py holds
+    the oracle to them as well)."""
+    G = _fuzz_golden()
+    seed, cam, world = G.build(kind, i)
+    want, ref_t = G.RGB[kind][i], G.HIT_T[kind][i]
+    near = ~(np.isfinite(ref_t) & (ref_t > 60.0))          # fp32 is not asked to resolve patterns on a floor hundreds of units away
+    with _ffi.Scene(compile_scene(world), device=0) as sc:
+        rgb, ids = sc.render(cam, precision="fp64", want_ids=True)
+        f32, _ = sc.render(cam, precision="fp32")
+    assert np.array_equal(np.isfinite(want).all(axis=2), np.isfinite(rgb).all(axis=2))
+    ok = np.isfinite(want).all(axis=2)
+    _exact("%s seed %d against the reference" % (kind, seed), oracle_cls(world), cam, rgb, want, None, None, ok)
+    assert frac_off_by_more_than_one(f32[ok & near], want[ok & near]) <= FP32_WORST
+
+
 def _mesh(rng, n_u, n_v, smooth):
     """A bumpy tessellated ellipsoid as a group of (smooth) triangles under its own transform."""
     radii = rng.uniform(0.6, 1.4, 3)
@@ -261,17 +307,13 @@ def _mesh(rng, n_u, n_v, smooth):
                 if np.linalg.norm(np.cross(pb - pa, pc - pa)) < 1e-9:
                     continue                                             # the degenerate triangles at the poles
                 if smooth:
-                    tris.append(S.SmoothTriangle(mat, None, point(*pa), point(*pb), point(*pc), normal(pa), normal(pb), normal(pc)))
+                    tris.append(S.SmoothTriangle(mat, _identity(), point(*pa), point(*pb), point(*pc), normal(pa), normal(pb), normal(pc)))
                 else:
-                    tris.append(S.Triangle(mat, None, point(*pa), point(*pb), point(*pc)))
+                    tris.append(S.Triangle(mat, _identity(), point(*pa), point(*pb), point(*pc)))
     return S.Group(S.Material(), _transform(rng), tris)
 
 
-@pytest.mark.parametrize("seed", range(8))
-def test_random_mesh_world(seed, oracle_cls):
-    """Triangle-BVH route: a tessellated mesh (flat or smooth, possibly glass or mirror) among a few primitives -- host-built
-    tree against the oracle, then the GPU-built tree and a refit of it against the host-built one, then a random subset of
-    tiles against the same pixels of the full frame."""
+def random_mesh_world(seed):
     rng = np.random.default_rng(1000 + seed)
     _SPREAD[0] = 1.2
     objs = [_mesh(rng, int(rng.integers(6, 12)), int(rng.integers(8, 16)), smooth=bool(seed % 2))]
@@ -284,7 +326,16 @@ def test_random_mesh_world(seed, oracle_cls):
         lights.append(AreaLight(point(-3, 6, -2), vector(1, 0, 0), 2, vector(0, 0, 1), 2, False, _rgb(rng, 0.3, 0.8)))
     w, h = 71, 45                                                          # not multiples of the 32-pixel tile or the 8-pixel block
     cam = Camera(w, h, 0.9, view_transform(point(0.5, 1.8, -6.0), point(0, 0, 0), vector(0, 1, 0)))
-    world = World(lights, objs)
+    return cam, World(lights, objs), rng
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_mesh_world(seed, oracle_cls):
+    """Triangle-BVH route: a tessellated mesh (flat or smooth, possibly glass or mirror) among a few primitives -- host-built
+    tree against the oracle, then the GPU-built tree and a refit of it against the host-built one, then a random subset of
+    tiles against the same pixels of the full frame."""
+    cam, world, rng = random_mesh_world(seed)
+    w, h = cam.hsize, cam.vsize
     xs, ys = np.meshgrid(np.arange(w), np.arange(h), indexing="ij")
     orc = oracle_cls(world)
     want, leaf, t_hit, _ = orc.render_pixels(cam, xs.ravel(), ys.ravel())
@@ -330,13 +381,10 @@ def _csg_tree(rng, depth, anchor):
         p.transform = anchor * translation(*rng.uniform(-0.5, 0.5, 3)) * rotation_y(rng.uniform(0, 6.28)) * scaling(*rng.uniform(0.6, 1.3, 3))
         return p
     op = [S.CSGUnion, S.CSGIntersect, S.CSGDifference][rng.integers(3)]
-    return S.CSG(_material(rng), None, op, operand(depth), operand(depth))
+    return S.CSG(_material(rng), _identity(), op, operand(depth), operand(depth))
 
 
-@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("RTC_FUZZ_SEEDS", "16"))))
-def test_random_csg_world(seed, oracle_cls):
-    """CSG route: one to three nested CSG trees (operands: primitives, groups, CSG), transparent and reflective parts,
-    a floor and sometimes an extra primitive, so that both CSG-only (single item) and mixed scenes occur."""
+def random_csg_world(seed):
     rng = np.random.default_rng(5000 + seed)
     _SPREAD[0] = 1.0
     objs = []
@@ -351,7 +399,14 @@ def test_random_csg_world(seed, oracle_cls):
         objs.append(floor)
     lights = [point_light(point(*(rng.uniform(-5, 5, 3) + np.array([0, 7, -5]))), _rgb(rng, 0.5, 1.0))]
     cam = Camera(HSIZE, VSIZE, 0.9, view_transform(point(0.3, 2.5, -6.5), point(0, -0.2, 0), vector(0, 1, 0)))
-    world = World(lights, objs)
+    return cam, World(lights, objs)
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("RTC_FUZZ_SEEDS", "16"))))
+def test_random_csg_world(seed, oracle_cls):
+    """CSG route: one to three nested CSG trees (operands: primitives, groups, CSG), transparent and reflective parts,
+    a floor and sometimes an extra primitive, so that both CSG-only (single item) and mixed scenes occur."""
+    cam, world = random_csg_world(seed)
     xs, ys = np.meshgrid(np.arange(HSIZE), np.arange(VSIZE), indexing="ij")
     orc = oracle_cls(world)
     want, leaf, t_hit, rays = orc.render_pixels(cam, xs.ravel(), ys.ravel())
