@@ -166,7 +166,8 @@ def _ref_pixel_plain(xy):
 FUZZ_SEEDS = list(range(40)) + [110, 129, 215, 1595, 2004, 2267, 2393]
 
 
-FUZZ_KINDS = {"world": ("random_world", FUZZ_SEEDS), "csg": ("random_csg_world", list(range(16))), "mesh": ("random_mesh_world", list(range(8)))}
+FUZZ_KINDS = {"world": ("random_world", FUZZ_SEEDS), "csg": ("random_csg_world", list(range(16))), "mesh": ("random_mesh_world", list(range(8))),
+              "texture": ("random_texture_world", list(range(12)))}
 
 
 def make_fuzz(procs=8):

@@ -12,6 +12,8 @@ the pixels more than one 8-bit level off) holds on 97.8 % of 404 worlds measured
 with their causes.  Two defects this test found and that are fixed: the n1/n2 container pass counted the hit as its own predecessor when its t was recomputed one ulp lower (glass
 objects lost their refraction in fp32), and fp32 cap points of cylinders/cones fell outside the reference's 1e-6 cap test.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -45,8 +47,23 @@ def bind(mods=None):
         g[name] = getattr(m, name)
     for name in ("AreaLight", "Camera", "World", "point_light", "view_transform"):
         g[name] = getattr(r, name)
+    if mods is None:
+        g["_texture_canvas"] = lambda pixels: c.TextureCanvas(pixels=pixels)
+    else:                                  # the reference's TextureCanvas reads a file: the same texels, through a PNG
+        import tempfile
+        from PIL import Image
+        tmp = tempfile.mkdtemp(prefix="rtc_fuzz_tex_")
+
+        def from_file(pixels):
+            path = os.path.join(tmp, "t%d.png" % len(os.listdir(tmp)))
+            Image.fromarray(pixels).save(path)
+            return c.TextureCanvas(path)
+        g["_texture_canvas"] = from_file
 
 _SPREAD = [2.5]          # how far from the origin objects are scattered (smaller for worlds of few objects, so that they are in view)
+
+
+bind(None)
 
 
 def _identity():
@@ -77,9 +94,8 @@ def _simple_pattern(rng):
 def _uv_pattern(rng, images=False):
     r = rng.random()
     if images and r < 0.5:                               # an image texture (earth, skybox): random texels, odd sizes
-        from ray_tracer_challenge_amd.canvas import TextureCanvas
         h, w = int(rng.integers(3, 40)), int(rng.integers(3, 40))
-        return S.UVTexturePattern(TextureCanvas(pixels=rng.integers(0, 256, (h, w, 3)).astype(np.uint8)))
+        return S.UVTexturePattern(_texture_canvas(rng.integers(0, 256, (h, w, 3)).astype(np.uint8)))
     if r < 0.5:
         return S.UVChecker(_rgb(rng), _rgb(rng), int(rng.integers(2, 9)), int(rng.integers(2, 9)))
     return S.UVAlignCheck(_rgb(rng), _rgb(rng), _rgb(rng), _rgb(rng), _rgb(rng))
@@ -534,9 +550,9 @@ def random_texture_world(seed):
         if r < 0.3:
             pat = S.TextureMapPattern(_uv_pattern(rng, True), [S.PlaneUVMap, S.SphereUVMap][rng.integers(2)], _small_transform(rng))
         elif r < 0.6:
-            pat = S.CylinderMapPattern(_uv_pattern(rng, True), _uv_pattern(rng, True), transform=_small_transform(rng))
+            pat = S.CylinderMapPattern(_uv_pattern(rng, True), _uv_pattern(rng, True), S.CylinderUVMap, _small_transform(rng))
         else:
-            pat = S.CubeMapPattern(*[_uv_pattern(rng, True) for _ in range(6)], transform=_small_transform(rng))
+            pat = S.CubeMapPattern(*[_uv_pattern(rng, True) for _ in range(6)], S.CubeUVMap, _small_transform(rng))
         o.material.pattern = pat
         o.material.transparency = np.float64(0.0)
         o.material.reflective = np.float64(0.0)            # the subject is texel lookup; a mirror cone around the camera is chaos
