@@ -167,7 +167,7 @@ FUZZ_SEEDS = list(range(40)) + [110, 129, 215, 1595, 2004, 2267, 2393]
 
 
 FUZZ_KINDS = {"world": ("random_world", FUZZ_SEEDS), "csg": ("random_csg_world", list(range(16))), "mesh": ("random_mesh_world", list(range(8))),
-              "texture": ("random_texture_world", list(range(12)))}
+              "texture": ("random_texture_world", list(range(12))), "large_csg": ("large_csg_world", [0, 1, 2, 3])}
 
 
 def make_fuzz(procs=8):

@@ -444,18 +444,18 @@ def _glass(rng):
     return m
 
 
-@pytest.mark.parametrize("case", ["groups_of_spheres", "many_cylinders", "mesh_minus_sphere", "glass_clusters"])
-def test_csg_larger_than_the_hit_list(case, oracle_cls, monkeypatch):
-    """A CSG object whose leaves could put more than 32 intersections on one ray -- two groups of ten spheres, a dozen
-    capped cylinders and cones, a tessellated mesh cut by a sphere, overlapping glass clusters (the refraction container walk
-    inside the CSG) -- used to be refused at rtc_scene_create; the reference renders all of them (CSG.local_intersect over
-    arbitrary groups, shapes.py:366-388).  Such roots are evaluated without a hit list (csg_stream): against the oracle.
-    Then every CSG of an ordinary scene through the same code (RTC_CSG_STREAM_ALL): the same frame bit for bit."""
+LARGE_CSG_CASES = ["groups_of_spheres", "many_cylinders", "mesh_minus_sphere", "glass_clusters"]
+
+
+def large_csg_world(case):
+    """`case`: a name of LARGE_CSG_CASES or its index"""
+    if not isinstance(case, str):
+        case = LARGE_CSG_CASES[int(case)]
     rng = np.random.default_rng({"groups_of_spheres": 1, "many_cylinders": 2, "mesh_minus_sphere": 3, "glass_clusters": 4}[case])
     _SPREAD[0] = 0.9
 
     def cluster(n, make):
-        return S.Group(S.Material(), None, [make() for _ in range(n)])
+        return S.Group(S.Material(), _identity(), [make() for _ in range(n)])
 
     def ball(mat=None):
         return S.Sphere(mat or _material(rng), translation(*rng.uniform(-0.9, 0.9, 3)) * scaling(*rng.uniform(0.3, 0.6, 3)))
@@ -466,18 +466,29 @@ def test_csg_larger_than_the_hit_list(case, oracle_cls, monkeypatch):
             cls = S.Cylinder if rng.random() < 0.6 else S.Cone
             return cls(_material(rng), translation(*rng.uniform(-0.8, 0.8, 3)) * rotation_x(rng.uniform(0, 3)) * rotation_z(rng.uniform(0, 3)) *
                        scaling(0.25, 0.8, 0.25), minimum=-1.0, maximum=1.0, closed=True)
-        obj = S.CSG(S.Material(), None, S.CSGUnion, S.CSG(S.Material(), None, S.CSGIntersect, cluster(6, rod), S.Sphere(_material(rng), scaling(1.3, 1.3, 1.3))),
+        obj = S.CSG(S.Material(), _identity(), S.CSGUnion, S.CSG(S.Material(), _identity(), S.CSGIntersect, cluster(6, rod), S.Sphere(_material(rng), scaling(1.3, 1.3, 1.3))),
                     S.CSG(S.Material(), translation(0.3, 0, 0), S.CSGDifference, cluster(5, rod), S.Cube(_material(rng), scaling(0.5, 0.5, 0.5))))
     elif case == "mesh_minus_sphere":
         obj = S.CSG(S.Material(), rotation_x(0.3), S.CSGDifference, _mesh(rng, 7, 10, smooth=True),
                     S.Sphere(_glass(rng), translation(0.5, 0.4, -0.6) * scaling(0.8, 0.8, 0.8)))
     else:
-        obj = S.CSG(S.Material(), None, S.CSGUnion, cluster(9, lambda: ball(_glass(rng))), cluster(9, lambda: ball(_glass(rng))))
+        obj = S.CSG(S.Material(), _identity(), S.CSGUnion, cluster(9, lambda: ball(_glass(rng))), cluster(9, lambda: ball(_glass(rng))))
     floor = S.Plane(_material(rng), translation(0, -2.2, 0))
     floor.material.transparency = np.float64(0.0)
     lights = [point_light(point(-4, 6, -5), _rgb(rng, 0.6, 1.0)), point_light(point(5, 3, -4), _rgb(rng, 0.2, 0.5))]
     cam = Camera(HSIZE, VSIZE, 0.8, view_transform(point(0.4, 1.6, -5.5), point(0, 0, 0), vector(0, 1, 0)))
     world = World(lights, [obj, floor, ball()])
+    return cam, world
+
+
+@pytest.mark.parametrize("case", LARGE_CSG_CASES)
+def test_csg_larger_than_the_hit_list(case, oracle_cls, monkeypatch):
+    """A CSG object whose leaves could put more than 32 intersections on one ray -- two groups of ten spheres, a dozen
+    capped cylinders and cones, a tessellated mesh cut by a sphere, overlapping glass clusters (the refraction container walk
+    inside the CSG) -- used to be refused at rtc_scene_create; the reference renders all of them (CSG.local_intersect over
+    arbitrary groups, shapes.py:366-388).  Such roots are evaluated without a hit list (csg_stream): against the oracle.
+    Then every CSG of an ordinary scene through the same code (RTC_CSG_STREAM_ALL): the same frame bit for bit."""
+    cam, world = large_csg_world(case)
     cs = compile_scene(world)
     assert sum({0: 2, 1: 1, 2: 2, 3: 4, 4: 4, 5: 1}[int(k)] for k in cs.arrays["leaf_kind"][:cs.counts["n_leaves"] - 2]) > 32
     xs, ys = np.meshgrid(np.arange(HSIZE), np.arange(VSIZE), indexing="ij")

@@ -1,6 +1,7 @@
 """The CPU oracle against the REFERENCE on the random worlds of tests/test_gpu_fuzz.py: oracle/make_golden.py built the same
 worlds (same seeds, same draws) out of the reference's own classes and rendered them whole with the reference
-(tests/golden/fuzz_worlds.npz: 47 general worlds, 16 nested-CSG worlds, 8 tessellated-mesh worlds, 12 image-texture worlds).  This pins the oracle on
+(tests/golden/fuzz_worlds.npz: 47 general worlds, 16 nested-CSG worlds, 8 tessellated-mesh worlds, 12 image-texture worlds, the 4 CSG objects
+larger than the kernel's hit list).  This pins the oracle on
 what the scene fixtures do not hold -- shear chains, glass inside glass of other refractive indices, shadow-less objects, CSG
 of random operands three levels deep, smooth and flat meshes, pattern composites on every primitive -- so that the fuzz
 tests' "kernel == oracle" means "kernel == reference" there too."""
