@@ -4,17 +4,29 @@
 number of GPUs `render_multi` shards image tiles over.
 """
 
+# attribute, YAML key, default, conversion -- the whole schema
+_FIELDS = (("thread_count", "thread-count", 4, int),
+           ("timeout", "timeout", 30, int),
+           ("divide_threshold", "divide-threshold", 1, int),
+           ("clamping", "clamping", False, lambda v: v))
+
 
 class GlobalConfig(object):
-    def __init__(self, thread_count=4, timeout=30, divide_threshold=1, clamping=False):
-        self.thread_count = thread_count
-        self.timeout = timeout
-        self.divide_threshold = divide_threshold
-        self.clamping = clamping
+    def __init__(self, *args, **kwargs):
+        names = [f[0] for f in _FIELDS]
+        if len(args) > len(names):
+            raise TypeError("GlobalConfig takes at most %d arguments" % len(names))
+        given = dict(zip(names, args))
+        for k, v in kwargs.items():
+            if k not in names or k in given:
+                raise TypeError("GlobalConfig: unexpected or repeated argument %r" % k)
+            given[k] = v
+        for attr, _, default, _ in _FIELDS:
+            setattr(self, attr, given.get(attr, default))
 
     @classmethod
     def from_yaml(cls, obj):
-        return cls(thread_count=int(obj.get("thread-count", 4)),
-                   timeout=int(obj.get("timeout", 30)),
-                   divide_threshold=int(obj.get("divide-threshold", 1)),
-                   clamping=obj.get("clamping", False))
+        return cls(**{attr: conv(obj[key]) for attr, key, _, conv in _FIELDS if key in obj})
+
+    def __repr__(self):
+        return "GlobalConfig(%s)" % ", ".join("%s=%r" % (f[0], getattr(self, f[0])) for f in _FIELDS)

@@ -31,18 +31,26 @@ class OBJParser(object):
     def _parse_line(self, line):
         tok = line.split(" ")
         if "" in tok:
-            tok.remove("")
-        head = tok[0]
-        if head == "v":
-            self.vertices.append(point(float(tok[1]), float(tok[2]), float(tok[3])))
-        elif head == "vn":
-            self.normals.append(vector(float(tok[1]), float(tok[2]), float(tok[3])))
-        elif head == "f":
-            self.named_groups[self.current_group_name].add_child(self._fan_triangulation(tok))
-        elif head == "g":
-            if tok[1] not in self.named_groups:
-                self.named_groups[tok[1]] = Group(self.default_material, matrix4x4identity(), [])
-            self.current_group_name = tok[1]
+            tok.remove("")                               # the first empty token only (see the module docstring)
+        record = self._RECORDS.get(tok[0])
+        if record is not None:                           # every other record type is skipped
+            record(self, tok)
+
+    def _vertex(self, tok):
+        self.vertices.append(point(*[float(c) for c in tok[1:4]]))
+
+    def _normal(self, tok):
+        self.normals.append(vector(*[float(c) for c in tok[1:4]]))
+
+    def _face(self, tok):
+        self.named_groups[self.current_group_name].add_child(self._fan_triangulation(tok))
+
+    def _group(self, tok):
+        name = tok[1]
+        self.named_groups.setdefault(name, Group(self.default_material, matrix4x4identity(), []))
+        self.current_group_name = name
+
+    _RECORDS = {"v": _vertex, "vn": _normal, "f": _face, "g": _group}
 
     def _corner(self, token):
         """'v/t/n' -> (vertex index, normal index or None)."""
