@@ -86,6 +86,26 @@ __global__ __launch_bounds__(RTC_BLOCK, WAVES) void trace_kernel(rtc::DScene<R> 
     rtc::flush_counters(cnt, F, reinterpret_cast<unsigned int*>(s_stack));
 }
 
+// The per-wave ray counts of a launch (DFrame::work) added to the caller's five counters: a few blocks, five atomics each.
+__global__ __launch_bounds__(256) void sum_rays_kernel(const uint4* __restrict__ parts, int n_waves, unsigned long long* rays) {
+    __shared__ unsigned long long red[5][4];
+    unsigned long long s[5] = {0, 0, 0, 0, 0};
+    for (int w = blockIdx.x * 256 + threadIdx.x; w < n_waves; w += gridDim.x * 256) {
+        const uint4 a = parts[2 * (size_t)w];
+        const unsigned int e = reinterpret_cast<const unsigned int*>(parts + 2 * (size_t)w + 1)[0];
+        s[0] += a.x; s[1] += a.y; s[2] += a.z; s[3] += a.w; s[4] += e;
+    }
+    for (int k = 0; k < 5; k++) {
+        for (int off = 32; off > 0; off >>= 1) s[k] += __shfl_down(s[k], off, 64);
+        if ((threadIdx.x & 63) == 0) red[k][threadIdx.x >> 6] = s[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < 5) {
+        const unsigned long long t = red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
+        if (t) atomicAdd(rays + (threadIdx.x < 4 ? threadIdx.x : 12), t);
+    }
+}
+
 // Next frame's launch order from this frame's unit costs (one block; n is a few 10^4): entries in
 // descending cost by buckets of a quarter octave -- the launch cannot end before its longest wave
 // does, so the long ones go first -- and, from the second measured frame on, with the dearest units
@@ -341,6 +361,7 @@ struct Workspace {
     uint32_t* fb_cost = nullptr; int32_t* fb_order[2] = {nullptr, nullptr};
     long long fb_units = 0; int fb_cur = 0; bool fb_valid = false;
     int32_t* fb_used_dev = nullptr; int32_t* fb_used_host = nullptr;   // entries the current order really has (host copy: pinned)
+    uint32_t* ray_parts = nullptr;        // [n_entries][8]: the ray counts of every wave of the last launch (DFrame::work in the variants that count no work)
     hipEvent_t fb_used_event = nullptr; bool fb_used_known = false;
     // fp64 without CSG exists for 3 and for 2 waves per SIMD (trace_kernel's WAVES): once a view's order has settled, four
     // frames are timed -- 3, 2, 3, 2 waves; events around the launch, read when they have completed -- and the budget with the
@@ -556,6 +577,7 @@ int validate(const rtc_scene_desc& d) {
 // split units dearer than these x (total cost / wave slots) into 4 / 16 waves; 0 = never (development overrides: RTC_SPLIT4, RTC_SPLIT16)
 float g_split4 = [] { const char* e = getenv("RTC_SPLIT4"); return e ? (float)atof(e) : 0.5f; }();     // cost of a 4x4 part / cost of its unit; 0 = never split
 const bool g_replicas = [] { const char* e = getenv("RTC_REPLICAS"); return !e || atoi(e) != 0; }();     // RTC_REPLICAS=0: parts leave their spare lanes idle
+const bool g_ray_parts = [] { const char* e = getenv("RTC_RAY_PARTS"); return !e || atoi(e) != 0; }();   // RTC_RAY_PARTS=0: ray counts through atomics from every workgroup
 const bool g_tune_waves = [] { const char* e = getenv("RTC_TUNE_WAVES"); return !e || atoi(e) != 0; }();   // RTC_TUNE_WAVES=0: fp64 always at 3 waves per SIMD
 float g_split_t = [] { const char* e = getenv("RTC_SPLIT_T"); return e ? (float)atof(e) : 0.0f; }();
 float g_split16 = [] { const char* e = getenv("RTC_SPLIT16"); return e ? (float)atof(e) : 0.35f; }();     // the same for a 2x2 part
@@ -972,10 +994,11 @@ int launch(rtc_scene* scene, const rtc_camera* cam, const rtc_render_opts* opts,
                 HIP_TRY(hipMalloc(&p, (size_t)n_entries * sizeof(int32_t))); ws->fb_mem.ptrs.push_back(p); ws->fb_order[k] = (int32_t*)p;
             }
             HIP_TRY(hipMalloc(&p, sizeof(int32_t))); ws->fb_mem.ptrs.push_back(p); ws->fb_used_dev = (int32_t*)p;
+            HIP_TRY(hipMalloc(&p, (size_t)n_entries * 8 * sizeof(uint32_t))); ws->fb_mem.ptrs.push_back(p); ws->ray_parts = (uint32_t*)p;
             if (!ws->fb_used_host) HIP_TRY(hipHostMalloc((void**)&ws->fb_used_host, sizeof(int32_t), hipHostMallocDefault));
             if (!ws->fb_used_event) HIP_TRY(hipEventCreateWithFlags(&ws->fb_used_event, hipEventDisableTiming));
             ws->fb_used_known = false;
-            ws->fb_mem.bytes = (size_t)n_units * 4 + (size_t)n_entries * 8;
+            ws->fb_mem.bytes = (size_t)n_units * 4 + (size_t)n_entries * 40;
             ws->fb_units = n_units;
         }
         if (memcmp(&key, &ws->fb_key, sizeof(key)) != 0) { ws->fb_key = key; ws->fb_age = 0; ws->tune_stage = 0; ws->tune_two_waves = false; }
@@ -1018,8 +1041,17 @@ int launch(rtc_scene* scene, const rtc_camera* cam, const rtc_render_opts* opts,
         (void)hipGetLastError();       // a not-ready query is not an error
         if (ws->tune_stage == 6) two_waves = ws->tune_two_waves;
     }
+    // ray counts through per-wave slots instead of atomics (DFrame::work; every wave of the grid writes its slot, so nothing
+    // to clear) -- in the variants without CSG, which count no work
+    uint32_t* ray_parts = (ws && F.rays && g_ray_parts && !csg && !work_dev) ? ws->ray_parts : nullptr;
+    if (ray_parts) F.work = reinterpret_cast<unsigned long long*>(ray_parts);
     if (timing >= 0) HIP_TRY(hipEventRecord(ws->tune_ev[timing], stream));
     launch_trace(scene, cam, F, grid, precision, work_dev != nullptr, eps, eps_rel, stream, two_waves);
+    if (ray_parts) {
+        const int n_waves = (int)grid.x * (RTC_BLOCK / 64);
+        hipLaunchKernelGGL(sum_rays_kernel, dim3((unsigned)std::min(64, (n_waves + 255) / 256)), dim3(256), 0, stream,
+                           reinterpret_cast<const uint4*>(ray_parts), n_waves, F.rays);
+    }
     if (timing >= 0) HIP_TRY(hipEventRecord(ws->tune_ev[timing + 1], stream));
     HIP_TRY(hipGetLastError());
     if (feedback && resort) {

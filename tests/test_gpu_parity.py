@@ -300,7 +300,8 @@ def test_launch_order_feedback_changes_nothing(name, size, scenes):
             got, ids = sc.render(cam, precision=prec, want_ids=True, stats=st)
             np.testing.assert_array_equal(got, plain)
             np.testing.assert_array_equal(ids, ids0)
-            assert st["rays"] == s0["rays"]
+            assert st["rays"] == s0["rays"]        # per-wave count slots + sum_rays_kernel against the workgroups' atomics of the plain launch
+            assert st["shadow_rays_culled"] == s0["shadow_rays_culled"]
     # a different view on the same handle starts over from whatever order is there: still identical
     cam2 = cam.resized(cam.hsize // 2, cam.vsize // 2)
     a, _ = sc.render(cam2, precision="fp64", feedback=False)

@@ -3,6 +3,8 @@ One child process per variant (the library is loaded once per process); prints s
 import hashlib, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CASES = [("dragons", 1920, 1080), ("teapot", 1920, 1080), ("earth", 1920, 1080), ("dragons", 480, 192), ("cover", 1920, 1080), ("shadow_glamour_shot", 1200, 480)]
+if os.environ.get("AB_CASES"):      # e.g. AB_CASES=0,1,3
+    CASES = [CASES[int(k)] for k in os.environ["AB_CASES"].split(",")]
 if len(sys.argv) > 1 and sys.argv[1] == "--child":
     sys.path.insert(0, ROOT)
     import numpy as np
@@ -21,8 +23,8 @@ if len(sys.argv) > 1 and sys.argv[1] == "--child":
                     st = {}
                     sc.render(cam, precision=prec, stats=st)
                     ms.append(st["kernel_ms"])
-                row.append("%s %.3f ms (%s %s)" % (prec, sorted(ms[9:])[len(ms[9:]) // 2], hashlib.sha256(np.ascontiguousarray(rgb).tobytes()).hexdigest()[:8],
-                                                  hashlib.sha256(np.ascontiguousarray(ids).tobytes()).hexdigest()[:8]))
+                row.append("%s %.3f ms (%s %s, %d+%d rays)" % (prec, sorted(ms[9:])[len(ms[9:]) // 2], hashlib.sha256(np.ascontiguousarray(rgb).tobytes()).hexdigest()[:8],
+                                                  hashlib.sha256(np.ascontiguousarray(ids).tobytes()).hexdigest()[:8], sum(st["rays"]), st["shadow_rays_culled"]))
             print("  %-22s %s" % ("%s@%dx%d" % (name, w, h), "  ".join(row)), flush=True)
     sys.exit(0)
 for v in sys.argv[1:]:
