@@ -1,5 +1,5 @@
 """Wave timeline of one frame from a -DRTC_TIMELINE build (development aid).
-Usage: timeline.py lib.so scene W H"""
+Usage: timeline.py lib.so scene W H [frames]"""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -12,7 +12,7 @@ name, w, h = sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
 cam, world, _ = load_world(os.path.join(ROOT, "scenes", name + ".npz"))
 cam = cam.resized(w, h)
 with _ffi.Scene(compile_scene(world)) as sc:
-    for _ in range(3):
+    for _ in range(int(sys.argv[5]) if len(sys.argv) > 5 else 3):
         st = {}
         rgb, _ = sc.render(cam, precision="fp64", stats=st)
 print("kernel_ms", st["kernel_ms"])
