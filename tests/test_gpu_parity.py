@@ -195,6 +195,29 @@ def test_device_pointer_path_and_quantize_kernel(scenes):
         np.testing.assert_array_equal(out.cpu().numpy(), quantize(host, clamp))
 
 
+@pytest.mark.parametrize("name,size", [("teapot", (480, 270)), ("csg_test", (192, 192))])
+def test_device_path_accumulates_ray_counts(name, size, scenes):
+    """`rays_dev` is added to, never cleared, by `rtc_render_device` (bench.py zeroes it once per timed loop): after k launches
+    it holds k frames' counts -- through the per-wave slots + sum_rays_kernel (scenes without CSG) and through the
+    workgroups' atomics (CSG scenes; and launches without feedback) alike, in every stage of the launch-order feedback."""
+    import torch
+    cam, world, sc = scenes(name)
+    cam = cam.resized(*size)
+    one = {}
+    sc.render(cam, precision="fp64", stats=one, feedback=False)
+    dev = torch.device("cuda", 0)
+    frame = torch.zeros((cam.hsize, cam.vsize, 3), dtype=torch.float64, device=dev)
+    rays = torch.zeros(13, dtype=torch.int64, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    for k in range(1, 9):
+        sc.render_device(cam, frame.data_ptr(), rays_ptr=rays.data_ptr(), precision="fp64", stream=stream)
+        torch.cuda.synchronize()
+        got = [int(v) for v in rays.tolist()]
+        assert got[:4] == [k * v for v in one["rays"]], k
+        assert got[12] == k * one["shadow_rays_culled"], k
+        assert got[4:12] == [0] * 8
+
+
 def test_render_api_and_multi(scenes):
     from ray_tracer_challenge_amd.canvas import construct_ppm
     from ray_tracer_challenge_amd.renderer import device_scenes, render, render_multi
