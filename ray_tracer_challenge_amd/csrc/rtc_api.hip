@@ -50,16 +50,17 @@ int fail(int code, const char* fmt, ...) {
 // -- tree walks want the waves, fp64 pattern arithmetic wants the registers -- and launch() times both for every view.
 #define RTC_WAVES_OF(R, CSG) ((CSG) ? 2 : sizeof(R) == 8 ? RTC_WAVES_F64 : RTC_WAVES_F32)
 template <class R, bool PROF, int CSG, bool FAR, bool REPL, int WAVES>
-__global__ __launch_bounds__(RTC_BLOCK, WAVES) void trace_kernel(rtc::DScene<R> S, rtc::DCamera<R> cam, rtc::DFrame F, R shade_eps, R shade_eps_rel) {
-    __shared__ int s_stack[RTC_BVH_STACK * RTC_BLOCK];
+__global__ __launch_bounds__((CSG > 0) ? RTC_BLOCK : RTC_BLOCK_PLAIN, WAVES) void trace_kernel(rtc::DScene<R> S, rtc::DCamera<R> cam, rtc::DFrame F, R shade_eps, R shade_eps_rel) {
+    using CNT = rtc::Counters<PROF, (CSG > 0), FAR, (CSG == 2), REPL>;
+    __shared__ int s_stack[RTC_BVH_STACK * CNT::kBlock];
     int* stack = s_stack + threadIdx.x;
     const int lane = threadIdx.x & 63;
-    rtc::Counters<PROF, (CSG > 0), FAR, (CSG == 2), REPL> cnt;
+    CNT cnt;
     rtc::zero_counters(cnt);
     const long long t_start = F.cost ? (long long)wall_clock64() : 0;
     bool lane_on;
     int pixel_lane;
-    const long long unit = rtc::wave_unit(F, lane_on, pixel_lane, cnt.rep, cnt.nrep);
+    const long long unit = rtc::wave_unit(F, lane_on, pixel_lane, cnt.rep, cnt.nrep, CNT::kBlock / 64);
     int x, y;
     size_t o;
     if (unit >= 0 && lane_on && rtc::work_pixel(F, cam.hsize, cam.vsize, unit * 64 + pixel_lane, x, y, o)) {
@@ -917,8 +918,10 @@ struct WorkspaceLease {
 // the trace kernel variant for (precision, counting, CSG / perturbed patterns) on `grid` workgroups
 void launch_trace(const rtc_scene* scene, const rtc_camera* cam, const rtc::DFrame& F, dim3 grid, int precision, bool prof, double eps, double eps_rel,
                   hipStream_t stream, bool two_waves = false) {
-    const dim3 block(RTC_BLOCK);
     const bool csg = scene->has_csg;
+    // `grid` counts RTC_BLOCK-thread blocks (4 entries of the launch order each); the variants without CSG run one entry per workgroup
+    const dim3 block(csg ? RTC_BLOCK : RTC_BLOCK_PLAIN);
+    grid = dim3(grid.x * (RTC_BLOCK / block.x));
     // a camera farther out than the boxes' padding covers (DScene::far_origin) gets the variants that re-base rays
     const double far_origin = scene->d64.far_origin;
     const bool far_cam = std::fabs(cam->inv_transform[3]) > far_origin || std::fabs(cam->inv_transform[7]) > far_origin || std::fabs(cam->inv_transform[11]) > far_origin;
@@ -978,7 +981,10 @@ int launch(rtc_scene* scene, const rtc_camera* cam, const rtc_render_opts* opts,
     bool resort = false;
     Workspace* ws = nullptr;
     WorkspaceLease lease = {scene, nullptr, stream};
-    if (feedback) {
+    // per-wave slots for the ray counts (DFrame::work) in the variants without CSG, which count no work: a launch without
+    // feedback takes a workspace for them too (one-wave workgroups would otherwise mean five atomics per wave)
+    const bool want_parts = rays_dev && g_ray_parts && !csg && !work_dev;
+    if (feedback || want_parts) {
         FbKey key;
         memset(&key, 0, sizeof(key));
         key.cam = *cam; key.precision = precision; key.depth = depth; key.tile_size = T; key.n_tiles = n_tiles; key.tile_ids = tile_ids_dev;
@@ -1001,6 +1007,11 @@ int launch(rtc_scene* scene, const rtc_camera* cam, const rtc_render_opts* opts,
             ws->fb_mem.bytes = (size_t)n_units * 4 + (size_t)n_entries * 40;
             ws->fb_units = n_units;
         }
+    }
+    if (feedback) {
+        FbKey key;
+        memset(&key, 0, sizeof(key));
+        key.cam = *cam; key.precision = precision; key.depth = depth; key.tile_size = T; key.n_tiles = n_tiles; key.tile_ids = tile_ids_dev;
         if (memcmp(&key, &ws->fb_key, sizeof(key)) != 0) { ws->fb_key = key; ws->fb_age = 0; ws->tune_stage = 0; ws->tune_two_waves = false; }
         resort = ws->fb_age < 2;
         ws->fb_age++;
@@ -1024,7 +1035,7 @@ int launch(rtc_scene* scene, const rtc_camera* cam, const rtc_render_opts* opts,
     // which of the two fp64 register budgets for this view (see Workspace::tune_ev)
     bool two_waves = false;
     int timing = -1;
-    if (ws && g_tune_waves && precision == 64 && !csg && !work_dev) {
+    if (ws && feedback && g_tune_waves && precision == 64 && !csg && !work_dev) {
         if (ws->tune_stage == 0 && !resort && ws->fb_valid && ws->fb_used_known) ws->tune_stage = 1;
         if (ws->tune_stage >= 1 && ws->tune_stage <= 4) {
             if (!ws->tune_ev[0]) for (hipEvent_t& e : ws->tune_ev) HIP_TRY(hipEventCreate(&e));
@@ -1043,7 +1054,7 @@ int launch(rtc_scene* scene, const rtc_camera* cam, const rtc_render_opts* opts,
     }
     // ray counts through per-wave slots instead of atomics (DFrame::work; every wave of the grid writes its slot, so nothing
     // to clear) -- in the variants without CSG, which count no work
-    uint32_t* ray_parts = (ws && F.rays && g_ray_parts && !csg && !work_dev) ? ws->ray_parts : nullptr;
+    uint32_t* ray_parts = (ws && want_parts) ? ws->ray_parts : nullptr;
     if (ray_parts) F.work = reinterpret_cast<unsigned long long*>(ray_parts);
     if (timing >= 0) HIP_TRY(hipEventRecord(ws->tune_ev[timing], stream));
     launch_trace(scene, cam, F, grid, precision, work_dev != nullptr, eps, eps_rel, stream, two_waves);
@@ -1294,6 +1305,7 @@ struct NoAllocScratch {
     uint32_t cost[RTC_NOALLOC_MAX_UNITS];
     int32_t order[2][RTC_NOALLOC_ENTRIES(RTC_NOALLOC_MAX_UNITS)];
     int32_t used;
+    uint32_t ray_parts[RTC_NOALLOC_ENTRIES(RTC_NOALLOC_MAX_UNITS)][8];      // per-wave ray counts (DFrame::work in the variants without CSG)
 };
 }  // namespace
 static __device__ __align__(256) unsigned char scratch[sizeof(NoAllocScratch)];
@@ -1364,7 +1376,14 @@ int rtc_render_device_noalloc(rtc_scene* scene, const rtc_camera* cam, const rtc
             grid = dim3((unsigned)(n_entries / (RTC_BLOCK / 64)));
         }
     }
+    uint32_t* ray_parts = (rays_dev && g_ray_parts && !scene->has_csg && !prof) ? &sp->ray_parts[0][0] : nullptr;      // every wave of the grid writes its slot
+    if (ray_parts) F.work = reinterpret_cast<unsigned long long*>(ray_parts);
     launch_trace(scene, cam, F, grid, precision, prof, eps, eps_rel, stream);
+    if (ray_parts) {
+        const int n_waves = (int)grid.x * (RTC_BLOCK / 64);
+        hipLaunchKernelGGL(sum_rays_kernel, dim3((unsigned)std::min(64, (n_waves + 255) / 256)), dim3(256), 0, stream,
+                           reinterpret_cast<const uint4*>(ray_parts), n_waves, F.rays);
+    }
     HIP_TRY(hipGetLastError());
     if (feedback && resort) {
         const int waves_per_simd = scene->has_csg ? 2 : (precision == 64 ? RTC_WAVES_F64 : RTC_WAVES_F32);

@@ -13,11 +13,23 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "../../include/rtc_api.h"
 
 #ifndef RTC_BLOCK
 #define RTC_BLOCK 256
+#endif
+// Threads per workgroup of the trace kernel variants without CSG: one wave.  A workgroup is admitted when ONE CU has a free
+// wave slot for each of its waves; the waves of a 256-thread workgroup end at different times, and the slots the early ones
+// free stay unusable until four are free on the same CU -- a quarter of the slots between 240 and 440 us of a dragons
+// launch (wave timelines, profiles/r02_experiments).  One-wave workgroups are admitted slot by slot: dragons 1080p fp64
+// 0.634 -> 0.60 ms, teapot 0.355 -> 0.326, earth 0.227 -> 0.189.  (Measured slower in round 1 and again early in round 2 --
+// "dispatch-bound" -- because every workgroup then added its ray counts with five atomics on one cache line, four times as
+// many of them; the counts now go through per-wave slots, DFrame::work.)  The CSG variants, which still count through
+// workgroup atomics, stay at RTC_BLOCK.  RTC_BLOCK counts units in the host code (4 units = 256 pixels of padding granularity).
+#ifndef RTC_BLOCK_PLAIN
+#define RTC_BLOCK_PLAIN 64
 #endif
 // __launch_bounds__ minimum waves per SIMD of the single-kernel form (register budget = 512 / waves).
 // Measured on MI355X (dragons / teapot / cover at 1080p): fp64 is fastest at 3 (168 VGPRs), fp32 at 4 (128).
@@ -176,8 +188,8 @@ struct DFrame {
 
 // the unit of this wave (-1 if there is none), which of its lanes take part, the pixel of the 8x8 block each lane has
 // (0..63, row-major) and which replica of that pixel the lane is (rep of nrep: 0 of 1 unless the part is replicated)
-__device__ __forceinline__ long long wave_unit(const DFrame& F, bool& lane_on, int& pixel_lane, int& rep, int& nrep) {
-    long long entry = (long long)blockIdx.x * (RTC_BLOCK / 64) + (threadIdx.x >> 6);
+__device__ __forceinline__ long long wave_unit(const DFrame& F, bool& lane_on, int& pixel_lane, int& rep, int& nrep, int waves_per_block = RTC_BLOCK / 64) {
+    long long entry = (long long)blockIdx.x * waves_per_block + (threadIdx.x >> 6);
     lane_on = true;
     pixel_lane = threadIdx.x & 63; rep = 0; nrep = 1;
     if (!F.order) return entry < F.n_units ? entry : -1;
@@ -215,6 +227,7 @@ template <bool PROF, bool CSG = true, bool FAR = false, bool STREAM = false, boo
     static constexpr bool kFar = FAR;
     static constexpr bool kStream = CSG && STREAM;
     static constexpr bool kReplicas = REPL;
+    static constexpr int kBlock = CSG ? RTC_BLOCK : RTC_BLOCK_PLAIN;      // threads per workgroup = stride of the per-lane traversal stack in LDS
     int rep, nrep;             // this lane is replica `rep` of `nrep` of its pixel (wave_unit); nrep is the same for the whole wave
     unsigned int c[5];         // primary, shadow, reflection, refraction rays traced; shadow rays not traced (light behind the surface)
     unsigned int w[PROF ? W_COUNT : 1];
@@ -507,7 +520,8 @@ struct PrimCode {
 // TRIS = false: the object BVH (leaves hold prim codes -> vis.prim); TRIS = true: the triangle
 // BVH (leaves are ranges of tb_* rows -> vis.tri).  Returns true if the visitor stopped it.
 template <class R, class V, bool TRIS>
-__device__ __forceinline__ bool traverse_bvh(const DScene<R>& S, const Ray<R>& ray, R tlo, V& vis, int* stack /* LDS, stride RTC_BLOCK */) {
+__device__ __forceinline__ bool traverse_bvh(const DScene<R>& S, const Ray<R>& ray, R tlo, V& vis, int* stack /* LDS, stride = threads per workgroup */) {
+    constexpr int kStride = std::remove_reference_t<decltype(vis.cnt)>::kBlock;
     const BvhNode* __restrict__ nodes = TRIS ? S.tnodes : S.nodes;
     // Box tests run in fp32 whatever R is: the boxes are padded outward by 2e-5 (relative, >= 2e-5
     // absolute) on the host, which covers rounding the ray to fp32, and the slab distances get a
@@ -587,7 +601,7 @@ __device__ __forceinline__ bool traverse_bvh(const DScene<R>& S, const Ray<R>& r
             if (h0 && h1) {
                 bool swap = near[1] < near[0];
                 int first = swap ? c1 : c0, second = swap ? c0 : c1;
-                stack[sp * RTC_BLOCK] = second; sp++;
+                stack[sp * kStride] = second; sp++;
                 node = first;
                 continue;
             } else if (h0) { node = c0; continue; }
@@ -602,7 +616,7 @@ __device__ __forceinline__ bool traverse_bvh(const DScene<R>& S, const Ray<R>& r
         }
         if (sp == 0) return false;
         sp--;
-        node = stack[sp * RTC_BLOCK];
+        node = stack[sp * kStride];
     }
 }
 
@@ -1446,7 +1460,8 @@ template <class R> __device__ __forceinline__ Ray<R> ray_for_pixel(const DCamera
 
 // block-level reduction of the ray / work counters, then a few atomics per block
 template <bool PROF, bool CSG, bool FAR, bool STREAM, bool REPL>
-__device__ __forceinline__ void flush_counters(Counters<PROF, CSG, FAR, STREAM, REPL>& cnt, const DFrame& F, unsigned int* red /* LDS, >= 5 * RTC_BLOCK/64 */) {
+__device__ __forceinline__ void flush_counters(Counters<PROF, CSG, FAR, STREAM, REPL>& cnt, const DFrame& F, unsigned int* red /* LDS, >= 5 * waves per workgroup */) {
+    constexpr int kWaves = Counters<PROF, CSG, FAR, STREAM, REPL>::kBlock / 64;
     if (!PROF && !CSG && F.rays && F.work) {          // per-wave slots (DFrame::work; the host sets it for the variants without CSG only)
         uint32_t* parts = reinterpret_cast<uint32_t*>(F.work);
         const int ln = threadIdx.x & 63;
@@ -1457,18 +1472,18 @@ __device__ __forceinline__ void flush_counters(Counters<PROF, CSG, FAR, STREAM, 
             v = __builtin_amdgcn_readfirstlane(v);
             if (ln == k) mine = v;
         }
-        if (ln < 8) parts[((size_t)blockIdx.x * (RTC_BLOCK / 64) + (threadIdx.x >> 6)) * 8 + ln] = mine;      // one 32-byte store per wave
+        if (ln < 8) parts[((size_t)blockIdx.x * kWaves + (threadIdx.x >> 6)) * 8 + ln] = mine;      // one 32-byte store per wave
     } else if (F.rays) {
         __syncthreads();
         for (int k = 0; k < 5; k++) {
             unsigned int v = cnt.c[k];
             for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-            if ((threadIdx.x & 63) == 0) red[k * (RTC_BLOCK / 64) + (threadIdx.x >> 6)] = v;
+            if ((threadIdx.x & 63) == 0) red[k * kWaves + (threadIdx.x >> 6)] = v;
         }
         __syncthreads();
         if (threadIdx.x < 5) {
             unsigned long long s = 0;
-            for (int q = 0; q < RTC_BLOCK / 64; q++) s += red[threadIdx.x * (RTC_BLOCK / 64) + q];
+            for (int q = 0; q < kWaves; q++) s += red[threadIdx.x * kWaves + q];
             if (s) atomicAdd(F.rays + (threadIdx.x < 4 ? threadIdx.x : 12), s);      // [4..11] are the work counters
         }
     }
