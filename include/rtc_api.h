@@ -246,7 +246,7 @@ int rtc_render_device(rtc_scene *scene, const rtc_camera *cam, const rtc_render_
 /* rtc_render_device for callers that cannot allocate -- code under HIP graph capture, tight serving loops,
  * harnesses that forbid hipMalloc.  No counterpart in the reference.  Same arguments, same frame bit for bit; it
  * calls no hipMalloc / hipFree / hipHostMalloc / event creation: the launch-order buffers of RTC_FLAG_NO_FEEDBACK's
- * comment (wave costs, two order lists: 1.3 MB) live in a device array inside the library, one copy per GPU, held
+ * comment (wave costs, two order lists, per-wave ray count slots: 4.9 MB) live in a device array inside the library, one copy per GPU, held
  * until the process ends.  Limit: 4 194 304 pixels (65 536 blocks of 8x8) per call, RTC_ERR_LIMIT beyond.  Every call
  * on a GPU shares that GPU's array (its costs are cleared by the call that records them; an order list is only read
  * by the view it was sorted for), so calls that overlap in time on one GPU -- different streams, or host threads
