@@ -1,5 +1,5 @@
 // rtc_api.hip -- the C ABI of include/rtc_api.h: scene upload, BVH build, kernel launches.
-// One translation unit, built by hipcc for gfx950 into librtc_hip.so.
+// Built by hipcc for gfx950 into librtc_hip.so together with rtc_trace_f64.hip (the fp64 trace kernels without CSG).
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -17,6 +17,7 @@
 #include "../../include/rtc_api.h"
 #include "rtc_bvh.hpp"
 #include "rtc_device.hpp"
+#include "rtc_trace_kernel.hpp"
 #include "rtc_lbvh_device.hpp"
 #include <rocprim/rocprim.hpp>
 
@@ -43,50 +44,6 @@ int fail(int code, const char* fmt, ...) {
 // ---------------------------------------------------------------------------------------------
 // kernels
 // ---------------------------------------------------------------------------------------------
-// CSG: 0 = the scene has no CSG object and no perturbed pattern, 1 = it has, 2 = and some CSG root is evaluated list-free
-// REPL: the pixels of split parts are traced by 4 or 16 lanes each (never with PROF)
-// WAVES: resident waves per SIMD the register budget is cut for (512 / WAVES registers per lane).  fp64 is built for 3 (168
-// registers, ~100 spilled) and, without CSG, for 2 as well (256 registers, none spilled): which is faster depends on the scene
-// -- tree walks want the waves, fp64 pattern arithmetic wants the registers -- and launch() times both for every view.
-#define RTC_WAVES_OF(R, CSG) ((CSG) ? 2 : sizeof(R) == 8 ? RTC_WAVES_F64 : RTC_WAVES_F32)
-template <class R, bool PROF, int CSG, bool FAR, bool REPL, int WAVES>
-__global__ __launch_bounds__((CSG > 0) ? RTC_BLOCK : RTC_BLOCK_PLAIN, WAVES) void trace_kernel(rtc::DScene<R> S, rtc::DCamera<R> cam, rtc::DFrame F, R shade_eps, R shade_eps_rel) {
-    using CNT = rtc::Counters<PROF, (CSG > 0), FAR, (CSG == 2), REPL>;
-    __shared__ int s_stack[RTC_BVH_STACK * CNT::kBlock];
-    int* stack = s_stack + threadIdx.x;
-    const int lane = threadIdx.x & 63;
-    CNT cnt;
-    rtc::zero_counters(cnt);
-    const long long t_start = F.cost ? (long long)wall_clock64() : 0;
-    bool lane_on;
-    int pixel_lane;
-    const long long unit = rtc::wave_unit(F, lane_on, pixel_lane, cnt.rep, cnt.nrep, CNT::kBlock / 64);
-    int x, y;
-    size_t o;
-    if (unit >= 0 && lane_on && rtc::work_pixel(F, cam.hsize, cam.vsize, unit * 64 + pixel_lane, x, y, o)) {
-        rtc::Ray<R> ray = rtc::ray_for_pixel(cam, x, y);
-        int hit_leaf;
-#ifdef RTC_TIMELINE
-        long long tl_start = wall_clock64();
-#endif
-        rtc::V3<R> c = rtc::trace_pixel(S, ray, F.max_depth, shade_eps, shade_eps_rel, stack, cnt, F.seed,
-                                        (uint32_t)(y * cam.hsize + x), hit_leaf);
-#ifdef RTC_TIMELINE   /* development build only (tools/timeline.py): start/end ticks (100 MHz) instead of the colour */
-        c.x = (R)(double)(tl_start & 0xFFFFFFFFFFLL); c.y = (R)(double)(wall_clock64() & 0xFFFFFFFFFFLL); c.z = R(0);
-#endif
-        if (cnt.rep == 0) {
-            cnt.c[0] = 1;
-            F.rgb[3 * o] = (double)c.x; F.rgb[3 * o + 1] = (double)c.y; F.rgb[3 * o + 2] = (double)c.z;
-            if (F.hit_id) F.hit_id[o] = hit_leaf;
-        } else cnt.c[2] = cnt.c[3] = 0;               // replicas trace the same camera, reflection and refraction rays: counted once
-    }
-    if (F.cost && unit >= 0 && lane == 0) {
-        long long dt = (long long)wall_clock64() - t_start;
-        atomicAdd(F.cost + unit, (uint32_t)(dt < 0 ? 0 : dt > 0x0FFFFFFFLL ? 0x0FFFFFFFLL : dt));
-    }
-    rtc::flush_counters(cnt, F, reinterpret_cast<unsigned int*>(s_stack));
-}
-
 // The per-wave ray counts of a launch (DFrame::work) added to the caller's five counters: a few blocks, five atomics each.
 __global__ __launch_bounds__(256) void sum_rays_kernel(const uint4* __restrict__ parts, int n_waves, unsigned long long* rays) {
     __shared__ unsigned long long red[5][4];
@@ -927,22 +884,27 @@ void launch_trace(const rtc_scene* scene, const rtc_camera* cam, const rtc::DFra
     const bool far_cam = std::fabs(cam->inv_transform[3]) > far_origin || std::fabs(cam->inv_transform[7]) > far_origin || std::fabs(cam->inv_transform[11]) > far_origin;
     const bool repl = F.replicas != 0 && !prof;
 #define RTC_LAUNCH_W(R, PROF, CSG, FAR, REPL, W, SC) \
-    hipLaunchKernelGGL((trace_kernel<R, PROF, CSG, FAR, REPL, W>), grid, block, 0, stream, SC, make_camera<R>(*cam), F, (R)eps, (R)eps_rel)
-#define RTC_LAUNCH_K(R, PROF, CSG, FAR, REPL, SC) do { \
-    if (sizeof(R) == 8 && !(PROF) && (CSG) == 0 && two_waves) RTC_LAUNCH_W(R, PROF, CSG, FAR, REPL, ((sizeof(R) == 8 && !(PROF) && (CSG) == 0) ? 2 : RTC_WAVES_OF(R, CSG)), SC); \
-    else RTC_LAUNCH_W(R, PROF, CSG, FAR, REPL, RTC_WAVES_OF(R, CSG), SC); } while (0)
-#ifdef RTC_DEV_PLAIN_ONLY   /* development builds (tools/build_variant.sh): only the variants the mesh scenes use -- seconds instead of minutes */
-#define RTC_LAUNCH_CSG(R, SC) do { (void)csg; (void)far_cam; if (prof) RTC_LAUNCH_K(R, true, 0, false, false, SC); \
-    else if (repl) RTC_LAUNCH_K(R, false, 0, false, true, SC); else RTC_LAUNCH_K(R, false, 0, false, false, SC); } while (0)
-#else
+    hipLaunchKernelGGL((rtc::trace_kernel<R, PROF, CSG, FAR, REPL, W>), grid, block, 0, stream, SC, make_camera<R>(*cam), F, (R)eps, (R)eps_rel)
+#define RTC_LAUNCH_K(R, PROF, CSG, FAR, REPL, SC) RTC_LAUNCH_W(R, PROF, CSG, FAR, REPL, RTC_WAVES_OF(R, CSG), SC)
 #define RTC_LAUNCH_REPL(R, CSG, FAR, SC) do { if (prof) RTC_LAUNCH_K(R, true, CSG, FAR, false, SC); \
     else if (repl) RTC_LAUNCH_K(R, false, CSG, FAR, true, SC); else RTC_LAUNCH_K(R, false, CSG, FAR, false, SC); } while (0)
+#ifdef RTC_DEV_PLAIN_ONLY   /* development builds (tools/build_variant.sh): only the variants the mesh scenes use -- seconds instead of minutes */
+#define RTC_LAUNCH_FAR(R, CSG, SC) do { (void)far_cam; RTC_LAUNCH_REPL(R, CSG, false, SC); } while (0)
+#define RTC_LAUNCH_CSG12(R, SC) do { } while (0)
+#else
 #define RTC_LAUNCH_FAR(R, CSG, SC) do { if (far_cam) RTC_LAUNCH_REPL(R, CSG, true, SC); else RTC_LAUNCH_REPL(R, CSG, false, SC); } while (0)
-#define RTC_LAUNCH_CSG(R, SC) do { \
-    if (!csg) RTC_LAUNCH_FAR(R, 0, SC); else if (!scene->has_csg_stream) RTC_LAUNCH_FAR(R, 1, SC); else RTC_LAUNCH_FAR(R, 2, SC); } while (0)
+#define RTC_LAUNCH_CSG12(R, SC) do { if (!scene->has_csg_stream) RTC_LAUNCH_FAR(R, 1, SC); else RTC_LAUNCH_FAR(R, 2, SC); } while (0)
 #endif
-    if (precision == 64) RTC_LAUNCH_CSG(double, scene->d64); else RTC_LAUNCH_CSG(float, scene->d32);
-#undef RTC_LAUNCH_CSG
+    if (precision == 64) {
+        // without CSG: the variants of rtc_trace_f64.hip (built without machine LICM, which parks hoisted fp64 constants in scratch)
+        if (!csg) rtc::launch_trace_f64_plain(prof, far_cam, repl, two_waves, grid, stream, scene->d64, make_camera<double>(*cam), F, eps, eps_rel);
+        else RTC_LAUNCH_CSG12(double, scene->d64);
+    } else {
+        if (!csg) RTC_LAUNCH_FAR(float, 0, scene->d32); else RTC_LAUNCH_CSG12(float, scene->d32);
+    }
+#undef RTC_LAUNCH_CSG12
+#undef RTC_LAUNCH_FAR
+#undef RTC_LAUNCH_REPL
 #undef RTC_LAUNCH_K
 #undef RTC_LAUNCH_W
 }
