@@ -225,7 +225,7 @@ def main():
                          "traffic_source": None if traffic is None else "profiles/traffic.json (stored: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
                                                                         "over this command, not measured in this run)",
                          "kernel": ("trace_kernel<double, false, 1, false, true, 2>" if cs.counts.get("n_csg_roots") else
-                                    "trace_kernel<double, false, 0, false, true, 3> (+ sum_rays_kernel, ~4 us, inside the same events)"),
+                                    "trace_kernel<double, false, 0, false, true, 4> (+ sum_rays_kernel, ~4 us, inside the same events)"),
                          "kernel_ms": round(kms64, 4),
                          "kernel_ms_source": "HIP events on the launch stream around each of the %d launches of the quoted repetition (mean); "
                                              "kernel_ms <= ms_per_step by construction" % args.steps,

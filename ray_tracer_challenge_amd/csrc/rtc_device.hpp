@@ -32,9 +32,12 @@
 #define RTC_BLOCK_PLAIN 64
 #endif
 // __launch_bounds__ minimum waves per SIMD of the single-kernel form (register budget = 512 / waves).
-// Measured on MI355X (dragons / teapot / cover at 1080p): fp64 is fastest at 3 (168 VGPRs), fp32 at 4 (128).
+// Measured on MI355X (dragons / teapot / cover at 1080p): fp32 is fastest at 4 (128 VGPRs).  fp64 without CSG, built without
+// machine LICM (rtc_trace_f64.hip), needs ~150 registers: at 4 (128 VGPRs, 18 - 40 spilled) it is as fast as at 3 on the
+// dragons and faster elsewhere (teapot 0.25 -> 0.22 ms); the variant compiled "for 2" uses 150 registers, spills nothing and
+// runs at 3 waves per SIMD in effect, and launch() times the two for every view (Workspace::tune_ev).
 #ifndef RTC_WAVES_F64
-#define RTC_WAVES_F64 3
+#define RTC_WAVES_F64 4
 #endif
 #ifndef RTC_WAVES_F32
 #define RTC_WAVES_F32 4

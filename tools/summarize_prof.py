@@ -13,11 +13,11 @@ c = sqlite3.connect(os.path.join(src, "kt", "kt_results.db"))
 lines.append("%-110s %6s %14s %12s %7s" % ("kernel", "calls", "total_us", "avg_us", "%"))
 for name, calls, total, avg, pct in c.execute("select name,total_calls,total_duration,average,percentage from top_kernels"):
     lines.append("%-110s %6d %14.3f %12.3f %7.2f" % (name[:110], calls, total, avg, pct))
-rows = [(e - b) / 1000.0 for b, e in c.execute("select start, end from kernels where name like '%trace_kernel<double, false, 0, false, true, 3>%' order by start")]
+rows = [(e - b) / 1000.0 for b, e in c.execute("select start, end from kernels where name like '%trace_kernel<double, false, 0, false, true, 4>%' order by start")]
 if rows:
     import statistics
-    lines += ["", "trace_kernel<double, false, 0, false, true, 3> (the steady-state variant: launch order with split units, 3 waves per SIMD) per launch, in launch order (us);",
-              "the first frames of a view -- cost measurement, plain order -- run trace_kernel<double, false, 0, false, false, 3>, and two timed frames the 2-wave variant, listed above:",
+    lines += ["", "trace_kernel<double, false, 0, false, true, 4> (the steady-state variant: launch order with split units, 4 waves per SIMD) per launch, in launch order (us);",
+              "the first frames of a view -- cost measurement, plain order -- run trace_kernel<double, false, 0, false, false, 4>, and two timed frames the 2-wave variant, listed above:",
               " ".join("%.0f" % r for r in rows[:40]) + (" ... (%d launches)" % len(rows) if len(rows) > 40 else ""),
               "median %.1f us, mean %.1f us, min %.1f us, max %.1f us over %d launches" % (
                   statistics.median(rows), statistics.mean(rows), min(rows), max(rows), len(rows))]
@@ -42,7 +42,7 @@ for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_mem", "pmc_cache"):
         traffic.setdefault(short, {})[cn] = avg
 # the steady-state kernel of the dragons frame is the variant for orders with split units (..., true>); the first frames of a
 # view (cost measurement, and the one before the host knows the order holds splits) run the plain variant
-k64 = next((v for k, v in traffic.items() if k.startswith("trace_kernel<double, false") and k.rstrip().endswith("true, 3>")), None) or \
+k64 = next((v for k, v in traffic.items() if k.startswith("trace_kernel<double, false") and k.rstrip().endswith("true, %d>" % 4)), None) or \
       next((v for k, v in traffic.items() if k.startswith("trace_kernel<double, false")), {})
 if "FETCH_SIZE" in k64 and "WRITE_SIZE" in k64:
     js = {"source": "profiles/%s_pmc.txt" % tag,
