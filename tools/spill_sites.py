@@ -1,9 +1,11 @@
 """Are there scratch loads / stores inside the BVH walks?  For every node fetch of a trace_kernel variant (the inline-asm scalar
 load marks it) the three innermost enclosing loops of the device assembly and the scratch accesses inside them.
-Usage: spill_sites.py [mangled-variant-substring]   (after tools/kres.py, which leaves the assembly in $TMPDIR/rtc_k.s)"""
+Usage: spill_sites.py [mangled-variant-substring [unit]]   (after tools/kres.py, which leaves the assembly of the two translation
+units in $TMPDIR/rtc_k_rtc_api.s and $TMPDIR/rtc_k_rtc_trace_f64.s; unit = rtc_api | rtc_trace_f64, default the fp64 one)"""
 import os, re, sys, tempfile
-variant = sys.argv[1] if len(sys.argv) > 1 else "trace_kernelIdLb0ELi0ELb0ELb1ELi3E"
-s = open(os.path.join(tempfile.gettempdir(), "rtc_k.s")).read().split("\n")
+variant = sys.argv[1] if len(sys.argv) > 1 else "trace_kernelIdLb0ELi0ELb0ELb1ELi4E"
+unit = sys.argv[2] if len(sys.argv) > 2 else "rtc_trace_f64"
+s = open(os.path.join(tempfile.gettempdir(), "rtc_k_%s.s" % unit)).read().split("\n")
 a = next(i for i, l in enumerate(s) if re.match(r"^_ZN.*%s.*:\s" % variant, l))
 b = next(i for i in range(a, len(s)) if "s_endpgm" in s[i])
 k = s[a:b]
