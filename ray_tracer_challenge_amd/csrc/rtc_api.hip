@@ -536,7 +536,7 @@ int validate(const rtc_scene_desc& d) {
 float g_split4 = [] { const char* e = getenv("RTC_SPLIT4"); return e ? (float)atof(e) : 0.5f; }();     // cost of a 4x4 part / cost of its unit; 0 = never split
 const bool g_replicas = [] { const char* e = getenv("RTC_REPLICAS"); return !e || atoi(e) != 0; }();     // RTC_REPLICAS=0: parts leave their spare lanes idle
 const bool g_ray_parts = [] { const char* e = getenv("RTC_RAY_PARTS"); return !e || atoi(e) != 0; }();   // RTC_RAY_PARTS=0: ray counts through atomics from every workgroup
-const bool g_tune_waves = [] { const char* e = getenv("RTC_TUNE_WAVES"); return !e || atoi(e) != 0; }();   // RTC_TUNE_WAVES=0: fp64 always at 3 waves per SIMD
+const bool g_tune_waves = [] { const char* e = getenv("RTC_TUNE_WAVES"); return !e || atoi(e) != 0; }();   // RTC_TUNE_WAVES=0: fp64 always the variant built for RTC_WAVES_F64 waves per SIMD
 float g_split_t = [] { const char* e = getenv("RTC_SPLIT_T"); return e ? (float)atof(e) : 0.0f; }();
 float g_split16 = [] { const char* e = getenv("RTC_SPLIT16"); return e ? (float)atof(e) : 0.35f; }();     // the same for a 2x2 part
 
