@@ -250,7 +250,9 @@ int rtc_render_device(rtc_scene *scene, const rtc_camera *cam, const rtc_render_
  * until the process ends.  Limit: 4 194 304 pixels (65 536 blocks of 8x8) per call, RTC_ERR_LIMIT beyond.  Every call
  * on a GPU shares that GPU's array (its costs are cleared by the call that records them; an order list is only read
  * by the view it was sorted for), so calls that overlap in time on one GPU -- different streams, or host threads
- * without stream order between them -- race on it: keep them stream-ordered, or use rtc_render_device. */
+ * without stream order between them -- race on it: keep them stream-ordered, or use rtc_render_device.
+ * On a stream that is being captured into a HIP graph the call renders in plain tile order and neither reads nor
+ * advances the launch-order state (a captured call runs when its graph is replayed, not when it is enqueued). */
 int rtc_render_device_noalloc(rtc_scene *scene, const rtc_camera *cam, const rtc_render_opts *opts,
                               int32_t n_tiles, const int32_t *tile_ids_dev,
                               double *rgb_dev, int32_t *hit_id_dev, int64_t *rays_dev, void *stream);

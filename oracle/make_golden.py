@@ -156,6 +156,31 @@ def make_jitter(size=(150, 60), seeds=(0, 1, 2, 3, 4, 5, 6, 7)):
         len(seeds), dt, means.std(axis=0, ddof=1).max(), 1 / 255.0), flush=True)
 
 
+def make_ppm(procs=8):
+    """The reference's own output files for cover/cover.yml: its frame from render_multi (renderer.py:795-835, the call
+    main.py:334 makes), then construct_ppm(ca) = final_clamped.ppm and construct_ppm(ca, False) = final.ppm
+    (main.py:348-354, canvas.py:133-181), byte for byte.  Pins rtc_render_ppm / canvas.construct_ppm to the reference's
+    bytes rather than to this repository's own quantize()."""
+    mods = rh.import_reference()
+    with rh.chdir(REF):
+        objs = mods["yaml_parser"].yaml_file_to_world_objects(os.path.join(REF, "cover/cover.yml"))
+        cam = objs["camera"]
+        world = mods["renderer"].World(objs["lights"], objs["world"])
+        t0 = time.time()
+        with tempfile.TemporaryDirectory() as tmp:
+            ca = mods["renderer"].render_multi(cam, world, procs, 600, tmp + "/", False)
+        dt = time.time() - t0
+    ca = np.array(ca, dtype=np.float64)
+    clamped = mods["canvas"].construct_ppm(ca)
+    scaled = mods["canvas"].construct_ppm(ca, False)
+    meta = {"scene_pack": "cover", "source": "cover/cover.yml", "hsize": int(cam.hsize), "vsize": int(cam.vsize), "remaining": 5,
+            "reference_seconds": round(dt, 1), "procs": procs, "frame_max": float(ca.max()),
+            "made_by": "oracle/make_golden.py make_ppm: reference render_multi -> construct_ppm(ca) and construct_ppm(ca, False), numpy %s" % np.__version__}
+    np.savez_compressed(os.path.join(GOLD, "cover_ppm.npz"), frame=ca, clamped=np.frombuffer(bytes(clamped), dtype=np.uint8),
+                        scaled=np.frombuffer(bytes(scaled), dtype=np.uint8), meta=np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8))
+    print("cover_ppm: %d x %d, %.1f s of the reference, %d + %d bytes, frame max %.4f" % (cam.hsize, cam.vsize, dt, len(clamped), len(scaled), ca.max()), flush=True)
+
+
 def _ref_pixel_plain(xy):
     R, S = _G["mods"]["renderer"], _G["mods"]["shapes"]
     r = R.ray_for_pixel(_G["cam"], xy[0], xy[1])
@@ -255,6 +280,7 @@ def main(which):
     jobs["dragons"] = dragons
     jobs["shadow_glamour_shot_jitter"] = make_jitter
     jobs["fuzz_worlds"] = make_fuzz
+    jobs["cover_ppm"] = make_ppm
 
     for name in (which or list(jobs)):
         jobs[name]()

@@ -419,11 +419,12 @@ int refresh_triangle_root_box(rtc_scene* sc, bool* grew) {
     double m = 0;
     for (int a = 0; a < 6; a++) m = std::max(m, (double)std::fabs(sc->d64.tbox[a]));
     if (!std::isfinite(m)) return fail(RTC_ERR_INVALID, "triangle rows are not finite");
-    *grew = m > sc->max_abs;
-    if (*grew) {
-        sc->max_abs = 1.5 * m;
-        sc->d64.far_origin = sc->d32.far_origin = (float)(2.0 * sc->max_abs);
-    }
+    // max_abs was taken from the boxes before padding, the root box here is padded (by at most 2e-5 relative, 2e-5 absolute,
+    // pad_boxes / lbvh_boxes_kernel): only an extent beyond that margin counts as growth.  far_origin stays where it is: it
+    // is tied to the extent the OBJECT boxes were padded for, which a triangle update does not re-pad -- a lower far_origin
+    // only re-bases more rays (FAR variants), it never culls.
+    *grew = m > sc->max_abs + 4e-5 * std::max(1.0, sc->max_abs);
+    if (*grew) sc->max_abs = 1.5 * m;
     return 0;
 }
 
@@ -956,6 +957,8 @@ int launch(rtc_scene* scene, const rtc_camera* cam, const rtc_render_opts* opts,
         if (ws->fb_units != n_units) {
             if (ws->used) HIP_TRY(hipStreamSynchronize(stream));        // frames that still read the old buffers
             ws->fb_mem.release(); ws->fb_mem.bytes = 0; ws->fb_units = 0; ws->fb_valid = false;
+            // the buffers of the old view are gone: whatever view comes next on this workspace starts over (costs, order, splits, tuning)
+            memset(&ws->fb_key, 0, sizeof(ws->fb_key)); ws->fb_age = 0; ws->tune_stage = 0; ws->tune_two_waves = false;
             void* p = nullptr;
             HIP_TRY(hipMalloc(&p, (size_t)n_units * sizeof(uint32_t))); ws->fb_mem.ptrs.push_back(p); ws->fb_cost = (uint32_t*)p;
             for (int k = 0; k < 2; k++) {
@@ -1000,10 +1003,20 @@ int launch(rtc_scene* scene, const rtc_camera* cam, const rtc_render_opts* opts,
     if (ws && feedback && g_tune_waves && precision == 64 && !csg && !work_dev) {
         if (ws->tune_stage == 0 && !resort && ws->fb_valid && ws->fb_used_known) ws->tune_stage = 1;
         if (ws->tune_stage >= 1 && ws->tune_stage <= 4) {
-            if (!ws->tune_ev[0]) for (hipEvent_t& e : ws->tune_ev) HIP_TRY(hipEventCreate(&e));
-            timing = 2 * (ws->tune_stage - 1);
-            two_waves = (ws->tune_stage & 1) == 0;
-            ws->tune_stage++;
+            if (!ws->tune_ev[0]) {
+                bool made = true;
+                for (hipEvent_t& e : ws->tune_ev) made = made && hipEventCreate(&e) == hipSuccess;
+                if (!made) {         // all eight or none: this view keeps the default budget
+                    for (hipEvent_t& e : ws->tune_ev) { if (e) (void)hipEventDestroy(e); e = nullptr; }
+                    (void)hipGetLastError();
+                    ws->tune_stage = 6; ws->tune_two_waves = false;
+                }
+            }
+            if (ws->tune_stage <= 4) {
+                timing = 2 * (ws->tune_stage - 1);
+                two_waves = (ws->tune_stage & 1) == 0;
+                ws->tune_stage++;
+            }
         } else if (ws->tune_stage == 5 && hipEventQuery(ws->tune_ev[7]) == hipSuccess) {
             float ms[4] = {0.0f, 0.0f, 0.0f, 0.0f};
             bool ok = true;
@@ -1318,7 +1331,15 @@ int rtc_render_device_noalloc(rtc_scene* scene, const rtc_camera* cam, const rtc
     F.n_units = (int32_t)n_units; F.n_entries = (int32_t)n_units;
     dim3 grid((unsigned)blocks);
     const long long n_entries = RTC_NOALLOC_ENTRIES(n_units);
-    const bool feedback = !(opts && (opts->flags & RTC_FLAG_NO_FEEDBACK));
+    bool feedback = !(opts && (opts->flags & RTC_FLAG_NO_FEEDBACK));
+    {
+        // Under HIP graph capture nothing executes when it is enqueued, so the host-side record of "the order kernel of call
+        // k has run before call k + 1 reads its list" does not hold (a captured call may be replayed later, never, or many
+        // times): captured calls render in plain order and leave the launch-order state alone.
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (stream && hipStreamIsCapturing(stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) feedback = false;
+        (void)hipGetLastError();
+    }
     bool resort = false;
     if (feedback) {
         FbKey key;

@@ -344,7 +344,8 @@ template <class R> __device__ __forceinline__ bool tri_hit(const R* __restrict__
             typedef double d8v __attribute__((ext_vector_type(8)));
             typedef double d2v __attribute__((ext_vector_type(2)));
             d8v a; d2v b;
-            asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx4 %1, %2, 0x40\n\ts_waitcnt lgkmcnt(0)" : "=s"(a), "=s"(b) : "s"(g0) : "memory");
+            // early-clobber outputs: both loads read the address pair, which must not be handed out as (part of) a destination
+            asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx4 %1, %2, 0x40\n\ts_waitcnt lgkmcnt(0)" : "=&s"(a), "=&s"(b) : "s"(g0) : "memory");
 #pragma unroll
             for (int k = 0; k < 8; k++) row[k] = (R)a[k];
             row[8] = (R)b[0]; row[9] = (R)b[1];
@@ -352,7 +353,7 @@ template <class R> __device__ __forceinline__ bool tri_hit(const R* __restrict__
             typedef float f8v __attribute__((ext_vector_type(8)));
             typedef float f2v __attribute__((ext_vector_type(2)));
             f8v a; f2v b;
-            asm volatile("s_load_dwordx8 %0, %2, 0x0\n\ts_load_dwordx2 %1, %2, 0x20\n\ts_waitcnt lgkmcnt(0)" : "=s"(a), "=s"(b) : "s"(g0) : "memory");
+            asm volatile("s_load_dwordx8 %0, %2, 0x0\n\ts_load_dwordx2 %1, %2, 0x20\n\ts_waitcnt lgkmcnt(0)" : "=&s"(a), "=&s"(b) : "s"(g0) : "memory");
 #pragma unroll
             for (int k = 0; k < 8; k++) row[k] = (R)a[k];
             row[8] = (R)b[0]; row[9] = (R)b[1];

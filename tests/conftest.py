@@ -105,6 +105,48 @@ def explain_mismatches(orc, cam, px, py, got_rgb, want_rgb, got_ids=None, want_i
     return unexplained, classes
 
 
+def record_classes(label, n_pixels, classes, unexplained=0):
+    """One line per parity comparison into gpurun_out/parity_classes.txt (copied to profiles/parity_classes.txt, tracked):
+    how many of the compared pixels differed from the oracle / the reference fixture and which of SURVEY.md 8d's classes
+    (tie, grazing, acne -- and `edge`, see explain_mismatches) explained them."""
+    path = os.environ.get("RTC_PARITY_CLASSES", os.path.join(ROOT, "gpurun_out", "parity_classes.txt"))
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, "a") as f:
+            f.write("%-64s pixels %7d  tie %4d  grazing %4d  acne %4d  edge %4d  unexplained %d\n" % (
+                label, n_pixels, classes["tie"], classes["grazing"], classes["acne"], classes["edge"], unexplained))
+    except OSError:
+        pass
+
+
+def walk_triangles(world):
+    """Every Triangle / SmoothTriangle of a world, depth first (groups' children, CSG operands)."""
+    out, todo = [], list(world.contains)[::-1]
+    while todo:
+        o = todo.pop()
+        if hasattr(o, "children"):
+            todo.extend(list(o.children)[::-1])
+        elif hasattr(o, "left"):
+            todo.extend([o.right, o.left])
+        elif hasattr(o, "p1"):
+            out.append(o)
+    return out
+
+
+def move_triangles(world, fn):
+    """Moves every triangle vertex of `world` IN PLACE by p -> fn(p) (object space of the triangle, (n, 3) arrays in,
+    (n, 3) out); the tree, the transforms and everything else stay.  The moved world is then an ordinary world: the oracle
+    walks it, compile_scene flattens it to the rows rtc_scene_update_triangles takes."""
+    from ray_tracer_challenge_amd.vector import point
+    tris = walk_triangles(world)
+    for k in ("p1", "p2", "p3"):
+        pts = np.array([np.asarray(getattr(getattr(t, k), "arr", getattr(t, k)), dtype=np.float64)[:3] for t in tris])
+        new = fn(pts)
+        for t, q in zip(tris, new):
+            setattr(t, k, point(float(q[0]), float(q[1]), float(q[2])))
+    return world
+
+
 @pytest.fixture(scope="session")
 def oracle_cls():
     from oracle.oracle import Oracle, build

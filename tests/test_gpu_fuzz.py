@@ -17,7 +17,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import explain_mismatches, frac_off_by_more_than_one
+from conftest import explain_mismatches, frac_off_by_more_than_one, move_triangles, record_classes
 from ray_tracer_challenge_amd import _ffi
 from ray_tracer_challenge_amd import shapes as S
 from ray_tracer_challenge_amd.canvas import color
@@ -178,6 +178,8 @@ def _exact(what, orc, cam, rgb, want, ids=None, leaf=None, ok=None, remaining=5,
     unexplained, classes = explain_mismatches(orc, cam, xs[sel], ys[sel], rgb[sel], want[sel], None if ids is None else ids[sel],
                                               None if leaf is None else leaf[sel], remaining=remaining, tol=tol)
     print("%s: differing and explained %s, unexplained %d" % (what, classes, len(unexplained)))
+    if "tree" in what:
+        record_classes("fuzz: " + what, int(sel.sum()), classes, len(unexplained))
     assert not unexplained, "%s: pixels that differ from the oracle without being tie / grazing / acne / edge: %s" % (what, unexplained[:12])
     assert sum(classes.values()) <= allowed * sel.sum() + 1
 
@@ -374,10 +376,26 @@ def test_random_mesh_world(seed, oracle_cls):
         assert (canvas_ids == -7).sum() == w * h - sum(min(32, w - (int(t) % 3) * 32) * min(32, h - (int(t) // 3) * 32) for t in tiles)
         sc.build_bvh_on_device()
         g, gi = sc.render(cam, precision="fp64", want_ids=True)
-        assert (np.abs(g - rgb).max(axis=2) > 1e-9).mean() <= 0.004 and (gi != ids).mean() <= 0.004
+        _exact("mesh seed %d, GPU-built tree" % seed, orc, cam, g, want, gi, leaf)           # the gate: the oracle, as for the host-built tree
+        g32, _ = sc.render(cam, precision="fp32")
+        assert frac_off_by_more_than_one(g32[near], want[near]) <= 0.005
+        assert (np.abs(g - rgb).max(axis=2) > 1e-9).mean() <= 0.004 and (gi != ids).mean() <= 0.004      # extra: host tree against GPU tree
         sc.update_triangles(cs.arrays["tri_geom"], cs.arrays["tri_norm"], refit=True)      # same rows: same boxes, same frame
         r, ri = sc.render(cam, precision="fp64", want_ids=True)
         np.testing.assert_array_equal(r, g)
+        # the mesh moved (every vertex by its own amount, object space): rebuilt and refitted trees against the oracle of the moved world
+        moved_cam, moved_world, _ = random_mesh_world(seed)
+        shake = np.random.default_rng(77 + seed)
+        move_triangles(moved_world, lambda p: p + 0.25 * np.sin(2.0 * p[:, [2, 0, 1]]) + 0.01 * shake.standard_normal(p.shape))
+        mcs = compile_scene(moved_world)
+        morc = oracle_cls(moved_world)
+        mwant, mleaf, _, _ = morc.render_pixels(cam, xs.ravel(), ys.ravel())
+        mwant, mleaf = mwant.reshape(w, h, 3), mleaf.reshape(w, h)
+        for refit in (True, False):
+            sc.update_triangles(cs.arrays["tri_geom"], cs.arrays["tri_norm"], refit=False)      # back to the start, fresh GPU tree
+            sc.update_triangles(mcs.arrays["tri_geom"], mcs.arrays["tri_norm"], refit=refit)
+            m, mi = sc.render(cam, precision="fp64", want_ids=True)
+            _exact("mesh seed %d moved, GPU tree %s" % (seed, "refitted" if refit else "rebuilt"), morc, cam, m, mwant, mi, mleaf)
 
 
 def _csg_tree(rng, depth, anchor):
