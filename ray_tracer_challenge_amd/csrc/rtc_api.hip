@@ -359,6 +359,7 @@ struct rtc_scene {
     DeviceArena tbvh_mem;
     // for refits (same arena): triangle row at each BVH position, parent link of each node, arrival counters
     int32_t* d_tb_row = nullptr; int32_t* d_tparent = nullptr; uint32_t* d_tarrived = nullptr;
+    int n_tnodes4 = 0;       // records in d64.tnodes4 (host-built: compact; GPU-built: one per binary node, unused ones empty)
     double max_abs = 0;      // largest coordinate of any box the scene's trees were padded for (RTC_PAD_OF_EXTENT)
     // device-side frame, hit ids, counters and tile list of the host-buffer entry points, kept between calls
     std::mutex out_mutex;
@@ -687,6 +688,21 @@ int create_impl(const rtc_scene_desc& d, rtc_scene* sc) {
         if (int rc = A.upload(on.data(), on.size(), &S.nodes)) return rc;
         if (int rc = sc->tbvh_mem.upload(tn.data(), tn.size(), &S.tnodes)) return rc;
         F.nodes = S.nodes; F.tnodes = S.tnodes;
+        if (tbvh.n_nodes() > 0) {
+            // what rays walk: the same tree four children wide (rtc_bvh.hpp collapse_bvh4); the binary one stays for builds and refits
+            rtc::Bvh4 t4 = rtc::collapse_bvh4(tbvh, RTC_BVH_STACK - 1);
+            if (t4.stack_need > RTC_BVH_STACK - 1) return fail(RTC_ERR_LIMIT, "four-wide triangle BVH needs %d stack entries", t4.stack_need);
+            std::vector<float> b4 = pad_boxes<float>(t4.box, pad_abs);
+            std::vector<rtc::BvhNode4> n4((size_t)t4.n_nodes());
+            for (int i = 0; i < t4.n_nodes(); i++) {
+                memcpy(n4[i].box, &b4[24 * (size_t)i], 24 * sizeof(float));
+                for (int k = 0; k < 4; k++) { n4[i].child[k] = t4.child[4 * (size_t)i + k]; n4[i].src[k] = t4.src[4 * (size_t)i + k]; }
+            }
+            if (getenv("RTC_BVH_INFO")) fprintf(stderr, "[rtc] triangle BVH: %d binary nodes (depth %d) -> %d four-wide nodes, stack need %d\n", tbvh.n_nodes(), tbvh.depth, t4.n_nodes(), t4.stack_need);
+            if (int rc = sc->tbvh_mem.upload(n4.data(), n4.size(), &S.tnodes4)) return rc;
+            F.tnodes4 = S.tnodes4;
+            sc->n_tnodes4 = t4.n_nodes();
+        }
         if (int rc = sc->tbvh_mem.upload(tb_geom.data(), tb_geom.size(), &sc->d64.tb_geom)) return rc;
         std::vector<float> g32 = cast_vec<float>(tb_geom.data(), tb_geom.size());
         if (int rc = sc->tbvh_mem.upload(g32.data(), g32.size(), &sc->d32.tb_geom)) return rc;
@@ -694,7 +710,7 @@ int create_impl(const rtc_scene_desc& d, rtc_scene* sc) {
     if (int rc = upload_real<double>(d, bvh.box, sc->mem64, sc->d64)) return rc;
     if (int rc = upload_real<float>(d, bvh.box, sc->mem32, sc->d32)) return rc;
     if ((sc->d64.n_bvh_nodes > 0 && (!sc->d64.nodes || !sc->d64.bvh_prims || !sc->d32.nodes)) ||
-        (sc->d64.n_tnodes > 0 && (!sc->d64.tnodes || !sc->d64.tb_geom || !sc->d64.tb_leaf || !sc->d32.tnodes || !sc->d32.tb_geom)))
+        (sc->d64.n_tnodes > 0 && (!sc->d64.tnodes || !sc->d64.tnodes4 || !sc->d32.tnodes4 || !sc->d64.tb_geom || !sc->d64.tb_leaf || !sc->d32.tnodes || !sc->d32.tb_geom)))
         return fail(RTC_ERR_HIP, "internal: BVH arrays missing on the device");
     sc->has_csg = d.n_csg_roots > 0;
     for (int i = 0; i < d.n_instr; i++)
@@ -745,7 +761,7 @@ int rebuild_triangle_bvh_device(rtc_scene* sc, bool again = false) {
         A.ptrs.push_back(*out); A.bytes += bytes;
         return 0;
     };
-    void *p_nodes, *p_g64, *p_g32, *p_leaf, *p_row, *p_arr2, *p_boxes, *p_bounds, *p_keys, *p_sorted, *p_idx, *p_sidx, *p_lkeys, *p_pin, *p_pleaf, *p_arr, *p_deep, *p_tmp = nullptr;
+    void *p_nodes4, *p_height, *p_nodes, *p_g64, *p_g32, *p_leaf, *p_row, *p_arr2, *p_boxes, *p_bounds, *p_keys, *p_sorted, *p_idx, *p_sidx, *p_lkeys, *p_pin, *p_pleaf, *p_arr, *p_deep, *p_tmp = nullptr;
     const size_t n_nodes = (size_t)std::max(1, n_leaves - 1);
     int rc = 0;
     auto bail = [&](int code) { fresh.release(); temp.release(); return code; };
@@ -757,7 +773,8 @@ int rebuild_triangle_bvh_device(rtc_scene* sc, bool again = false) {
         (rc = alloc(temp, (size_t)n * sizeof(uint32_t), &p_idx)) || (rc = alloc(temp, (size_t)n * sizeof(uint32_t), &p_sidx)) ||
         (rc = alloc(temp, (size_t)n_leaves * sizeof(uint64_t), &p_lkeys)) || (rc = alloc(fresh, n_nodes * sizeof(int32_t), &p_pin)) ||
         (rc = alloc(temp, (size_t)n_leaves * sizeof(int32_t), &p_pleaf)) || (rc = alloc(temp, n_nodes * sizeof(uint32_t), &p_arr)) ||
-        (rc = alloc(temp, sizeof(int32_t), &p_deep)))
+        (rc = alloc(temp, sizeof(int32_t), &p_deep)) || (rc = alloc(fresh, n_nodes * sizeof(rtc::BvhNode4), &p_nodes4)) ||
+        (rc = alloc(temp, n_nodes * sizeof(int32_t), &p_height)))
         return bail(rc);
 #define TRY_B(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return bail(fail(RTC_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_))); } while (0)
     const uint32_t bounds_init[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u};
@@ -796,6 +813,12 @@ int rebuild_triangle_bvh_device(rtc_scene* sc, bool again = false) {
         TRY_B(hipMemcpy(&deepest, p_deep, sizeof(deepest), hipMemcpyDeviceToHost));      // also waits for the build
         if (n_leaves == 1 || deepest <= RTC_BVH_STACK - 1) break;
     }
+    // the four-wide form rays walk, collapsed from the binary tree on the device (heights first: what fits the traversal stack)
+    TRY_B(hipMemset(p_height, 0, n_nodes * sizeof(int32_t)));
+    if (n_leaves > 1)
+        hipLaunchKernelGGL(rtc::lbvh_height_kernel, grid_for(n_leaves), blk, 0, nullptr, n_leaves, (const int32_t*)p_pin, (const int32_t*)p_pleaf, (int32_t*)p_height);
+    hipLaunchKernelGGL(rtc::lbvh_collapse4_kernel, grid_for((long long)n_nodes), blk, 0, nullptr, (int)n_nodes, (const rtc::BvhNode*)p_nodes, (const int32_t*)p_pin,
+                       (const int32_t*)p_height, RTC_BVH_STACK - 1, (rtc::BvhNode4*)p_nodes4);
     hipLaunchKernelGGL(rtc::lbvh_reorder_kernel, grid_for(12LL * n), blk, 0, nullptr, n, (const uint32_t*)p_sidx, sc->d_titems, sc->d64.tri_geom,
                        sc->d32.tri_geom, sc->d64.tri_leaf, (double*)p_g64, (float*)p_g32, (int32_t*)p_leaf, (int32_t*)p_row);
     TRY_B(hipGetLastError());
@@ -809,6 +832,8 @@ int rebuild_triangle_bvh_device(rtc_scene* sc, bool again = false) {
     fresh.ptrs.clear();
     sc->d64.tnodes = sc->d32.tnodes = (const rtc::BvhNode*)p_nodes;
     sc->d64.n_tnodes = sc->d32.n_tnodes = (int32_t)n_nodes;
+    sc->d64.tnodes4 = sc->d32.tnodes4 = (const rtc::BvhNode4*)p_nodes4;
+    sc->n_tnodes4 = (int)n_nodes;
     sc->d64.tb_geom = (const double*)p_g64; sc->d32.tb_geom = (const float*)p_g32;
     sc->d64.tb_leaf = sc->d32.tb_leaf = (const int32_t*)p_leaf;
     sc->d_tb_row = (int32_t*)p_row; sc->d_tparent = (int32_t*)p_pin; sc->d_tarrived = (uint32_t*)p_arr2;
@@ -833,6 +858,8 @@ int refit_triangle_bvh_device(rtc_scene* sc, bool again = false) {
                        sc->d64.tri_geom, sc->d32.tri_geom, const_cast<double*>(sc->d64.tb_geom), const_cast<float*>(sc->d32.tb_geom));
     hipLaunchKernelGGL(rtc::bvh_refit_kernel, dim3((unsigned)((n_nodes + 255) / 256)), blk, 0, nullptr, n_nodes, const_cast<rtc::BvhNode*>(sc->d64.tnodes),
                        (const int32_t*)sc->d_tparent, sc->d64.tb_geom, sc->d_tarrived, RTC_PAD_OF_EXTENT * sc->max_abs);
+    hipLaunchKernelGGL(rtc::bvh4_refresh_kernel, dim3((unsigned)((sc->n_tnodes4 + 255) / 256)), blk, 0, nullptr, sc->n_tnodes4,
+                       const_cast<rtc::BvhNode4*>(sc->d64.tnodes4), sc->d64.tnodes);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
     bool grew = false;
@@ -872,6 +899,19 @@ struct WorkspaceLease {
         ws->stream = stream; ws->used = true; ws->claimed = false;
     }
 };
+
+// development (RTC_DEBUG_SYNC=1): wait for the stream after every kernel of a frame and say which one failed, with the
+// launch it was part of -- how round 3 looked for the CSG variants' fault of round 2
+const bool g_debug_sync = [] { const char* e = getenv("RTC_DEBUG_SYNC"); return e && atoi(e) != 0; }();
+int debug_sync(hipStream_t stream, const char* what, unsigned grid_x, const rtc::DFrame& F) {
+    if (!g_debug_sync) return 0;
+    hipError_t e = hipStreamSynchronize(stream);
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e == hipSuccess) return 0;
+    fprintf(stderr, "[rtc debug] %s failed: %s (grid %u, n_units %d, n_entries %d, n_slots %d, order %p, cost %p, work %p, replicas %d, tiles %d)\n", what,
+            hipGetErrorString(e), grid_x, F.n_units, F.n_entries, F.n_slots, (const void*)F.order, (void*)F.cost, (void*)F.work, F.replicas, F.n_tiles);
+    return fail(RTC_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
+}
 
 // the trace kernel variant for (precision, counting, CSG / perturbed patterns) on `grid` workgroups
 void launch_trace(const rtc_scene* scene, const rtc_camera* cam, const rtc::DFrame& F, dim3 grid, int precision, bool prof, double eps, double eps_rel,
@@ -925,7 +965,7 @@ int launch(rtc_scene* scene, const rtc_camera* cam, const rtc_render_opts* opts,
     F.n_tiles = n_tiles; F.tile_size = T; F.tiles_x = tiles_x; F.tile_ids = tile_ids_dev;
     F.rgb = rgb_dev; F.hit_id = hit_id_dev; F.rays = reinterpret_cast<unsigned long long*>(rays_dev);
     F.max_depth = depth; F.seed = opts ? opts->seed : 0;
-    F.replicas = 0;
+    F.replicas = 0; F.n_slots = 0;
     long long work = (long long)n_tiles * T * T;
     long long blocks = (work + RTC_BLOCK - 1) / RTC_BLOCK;
     if (blocks > 0x7FFFFFFFLL) return fail(RTC_ERR_LIMIT, "too many blocks");
@@ -946,7 +986,7 @@ int launch(rtc_scene* scene, const rtc_camera* cam, const rtc_render_opts* opts,
     WorkspaceLease lease = {scene, nullptr, stream};
     // per-wave slots for the ray counts (DFrame::work) in the variants without CSG, which count no work: a launch without
     // feedback takes a workspace for them too (one-wave workgroups would otherwise mean five atomics per wave)
-    const bool want_parts = rays_dev && g_ray_parts && !csg && !work_dev;
+    const bool want_parts = rays_dev && g_ray_parts && (!csg || RTC_CSG_SLOTS) && !work_dev;
     if (feedback || want_parts) {
         FbKey key;
         memset(&key, 0, sizeof(key));
@@ -1030,13 +1070,15 @@ int launch(rtc_scene* scene, const rtc_camera* cam, const rtc_render_opts* opts,
     // ray counts through per-wave slots instead of atomics (DFrame::work; every wave of the grid writes its slot, so nothing
     // to clear) -- in the variants without CSG, which count no work
     uint32_t* ray_parts = (ws && want_parts) ? ws->ray_parts : nullptr;
-    if (ray_parts) F.work = reinterpret_cast<unsigned long long*>(ray_parts);
+    if (ray_parts) { F.work = reinterpret_cast<unsigned long long*>(ray_parts); F.n_slots = (int32_t)n_entries; }
     if (timing >= 0) HIP_TRY(hipEventRecord(ws->tune_ev[timing], stream));
     launch_trace(scene, cam, F, grid, precision, work_dev != nullptr, eps, eps_rel, stream, two_waves);
+    if (int rc = debug_sync(stream, "trace_kernel", grid.x, F)) return rc;
     if (ray_parts) {
-        const int n_waves = (int)grid.x * (RTC_BLOCK / 64);
+        const int n_waves = (int)std::min<long long>((long long)grid.x * (RTC_BLOCK / 64), n_entries);
         hipLaunchKernelGGL(sum_rays_kernel, dim3((unsigned)std::min(64, (n_waves + 255) / 256)), dim3(256), 0, stream,
                            reinterpret_cast<const uint4*>(ray_parts), n_waves, F.rays);
+        if (int rc = debug_sync(stream, "sum_rays_kernel", grid.x, F)) return rc;
     }
     if (timing >= 0) HIP_TRY(hipEventRecord(ws->tune_ev[timing + 1], stream));
     HIP_TRY(hipGetLastError());
@@ -1045,6 +1087,7 @@ int launch(rtc_scene* scene, const rtc_camera* cam, const rtc_render_opts* opts,
         // kernel above may still be reading the current one)
         hipLaunchKernelGGL(order_kernel, dim3(1), dim3(1024), 0, stream, ws->fb_cost, ws->fb_order[1 - ws->fb_cur], (int)n_units,
                            (int)n_entries, scene->n_cus * 4 * waves_per_simd, ws->fb_age >= 2 ? g_split4 : 0.0f, g_split16, ws->fb_used_dev, g_split_t);   // the first measured frame ran in plain order: its costs only sort; the second ran sorted and unsplit: its costs decide the splits
+        if (int rc = debug_sync(stream, "order_kernel", grid.x, F)) return rc;
         ws->fb_used_known = false;
         HIP_TRY(hipMemcpyAsync(ws->fb_used_host, ws->fb_used_dev, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipEventRecord(ws->fb_used_event, stream));
@@ -1326,6 +1369,7 @@ int rtc_render_device_noalloc(rtc_scene* scene, const rtc_camera* cam, const rtc
     const bool prof = rays_dev && opts && (opts->flags & RTC_FLAG_COUNT_WORK);
     F.work = prof ? reinterpret_cast<unsigned long long*>(rays_dev + 4) : nullptr;
     F.max_depth = depth; F.seed = opts ? opts->seed : 0;
+    F.n_slots = 0;
     F.replicas = 0;      // this entry point never reads back whether the order holds split units, so their parts leave the spare lanes idle
     F.order = nullptr; F.cost = nullptr;
     F.n_units = (int32_t)n_units; F.n_entries = (int32_t)n_units;
@@ -1359,8 +1403,8 @@ int rtc_render_device_noalloc(rtc_scene* scene, const rtc_camera* cam, const rtc
             grid = dim3((unsigned)(n_entries / (RTC_BLOCK / 64)));
         }
     }
-    uint32_t* ray_parts = (rays_dev && g_ray_parts && !scene->has_csg && !prof) ? &sp->ray_parts[0][0] : nullptr;      // every wave of the grid writes its slot
-    if (ray_parts) F.work = reinterpret_cast<unsigned long long*>(ray_parts);
+    uint32_t* ray_parts = (rays_dev && g_ray_parts && (!scene->has_csg || RTC_CSG_SLOTS) && !prof) ? &sp->ray_parts[0][0] : nullptr;      // every wave of the grid writes its slot
+    if (ray_parts) { F.work = reinterpret_cast<unsigned long long*>(ray_parts); F.n_slots = (int32_t)RTC_NOALLOC_ENTRIES(RTC_NOALLOC_MAX_UNITS); }
     launch_trace(scene, cam, F, grid, precision, prof, eps, eps_rel, stream);
     if (ray_parts) {
         const int n_waves = (int)grid.x * (RTC_BLOCK / 64);

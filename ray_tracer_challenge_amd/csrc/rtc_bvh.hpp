@@ -175,6 +175,130 @@ private:
     }
 };
 
+// ---- four children per node ------------------------------------------------------------------------------------
+// The binary tree collapsed two levels at a time: a wide node starts as a binary node's two children, and the child box
+// with the largest area is replaced by its own two children until there are four (or only leaves are left).  A ray then
+// meets about half as many nodes -- half as many DEPENDENT fetches, which is what the walk waits for -- at four box tests
+// per node.  The traversal stack holds up to k - 1 pending children per level of a k-wide node, so a wide tree needs
+// more stack per level than a binary one: `budget` is the number of entries the walk may have pending at once, and a
+// node is only widened as far as the worst-case need of everything below it still fits (a binary node pushes one entry
+// per level, so a binary tree of depth <= budget always fits; deep, thin parts of a tree stay binary, the rest goes
+// four-wide).  need4(node) = (k - 1) + max over children need4(child) <= budget by construction.
+struct Bvh4 {
+    std::vector<double> box;        // [n_nodes][24]: child k lo xyz, hi xyz
+    std::vector<int32_t> child;     // [n_nodes][4]: >= 0 inner node, < 0 leaf code (as in Bvh), EMPTY = none
+    std::vector<int32_t> src;       // [n_nodes][4]: where the child's box lives in the binary tree, (binary node << 1) | side; -1 = none
+    int stack_need = 0;             // worst-case pending entries of a walk
+    int n_nodes() const { return (int)(child.size() / 4); }
+};
+
+class Bvh4Collapser {
+public:
+    static constexpr int32_t EMPTY = INT32_MIN;
+    Bvh4Collapser(const Bvh& b, int budget) : b_(b), budget_(budget) {}
+    Bvh4 run() {
+        Bvh4 out;
+        out_ = &out;
+        if (b_.n_nodes() == 0) return out;
+        need2_.assign((size_t)b_.n_nodes(), 0);
+        height(0);
+        emit(0, std::max(budget_, need2_[0]));
+        out.stack_need = need4(0);
+        return out;
+    }
+
+private:
+    const Bvh& b_;
+    int budget_;
+    Bvh4* out_ = nullptr;
+    std::vector<int> need2_;       // pending entries a binary walk below (and including) the node can have
+    struct Slot { int32_t ref; int32_t src; double box[6]; };
+
+    int height(int node) {
+        int h = 0;
+        for (int side = 0; side < 2; side++) {
+            const int32_t c = b_.child[2 * (size_t)node + side];
+            if (c >= 0) h = std::max(h, height(c));
+        }
+        return need2_[node] = h + 1;
+    }
+    static double area(const Slot& s) {
+        const double d[3] = {s.box[3] - s.box[0], s.box[4] - s.box[1], s.box[5] - s.box[2]};
+        if (d[0] < 0 || d[1] < 0 || d[2] < 0) return 0;
+        return 2 * (d[0] * d[1] + d[1] * d[2] + d[2] * d[0]);
+    }
+    Slot slot_of(int node, int side) const {
+        Slot s;
+        s.ref = b_.child[2 * (size_t)node + side];
+        s.src = (node << 1) | side;
+        for (int a = 0; a < 6; a++) s.box[a] = b_.box[12 * (size_t)node + 6 * side + a];
+        return s;
+    }
+    int emit(int bnode, int B) {
+        const int idx = out_->n_nodes();
+        out_->box.resize(out_->box.size() + 24);
+        out_->child.resize(out_->child.size() + 4);
+        out_->src.resize(out_->src.size() + 4);
+        Slot s[4];
+        int k = 0;
+        for (int side = 0; side < 2; side++)
+            if (b_.child[2 * (size_t)bnode + side] != EMPTY) s[k++] = slot_of(bnode, side);
+        while (k < 4) {
+            int best = -1;
+            double best_area = -1;
+            const int bound = B - k;            // what every child may still need once there are k + 1 of them
+            for (int i = 0; i < k; i++) {
+                if (s[i].ref < 0) continue;
+                bool ok = true;
+                for (int j = 0; j < k && ok; j++)
+                    if (j != i && s[j].ref >= 0 && need2_[s[j].ref] > bound) ok = false;
+                int grand = 0;
+                for (int side = 0; side < 2 && ok; side++) {
+                    const int32_t c = b_.child[2 * (size_t)s[i].ref + side];
+                    if (c == EMPTY) continue;
+                    grand++;
+                    if (c >= 0 && need2_[c] > bound) ok = false;
+                }
+                if (grand != 2) ok = false;
+                if (ok && area(s[i]) > best_area) { best_area = area(s[i]); best = i; }
+            }
+            if (best < 0) break;
+            const int node = s[best].ref;
+            for (int j = k; j > best + 1; j--) s[j] = s[j - 1];
+            s[best] = slot_of(node, 0);
+            s[best + 1] = slot_of(node, 1);
+            k++;
+        }
+        const int child_budget = B - (k - 1);
+        for (int i = 0; i < 4; i++) {
+            int32_t ref = EMPTY, src = -1;
+            double box[6] = {std::numeric_limits<double>::infinity(), std::numeric_limits<double>::infinity(), std::numeric_limits<double>::infinity(),
+                             -std::numeric_limits<double>::infinity(), -std::numeric_limits<double>::infinity(), -std::numeric_limits<double>::infinity()};
+            if (i < k) {
+                for (int a = 0; a < 6; a++) box[a] = s[i].box[a];
+                src = s[i].src;
+                ref = s[i].ref >= 0 ? emit(s[i].ref, child_budget) : s[i].ref;
+            }
+            out_->child[4 * (size_t)idx + i] = ref;
+            out_->src[4 * (size_t)idx + i] = src;
+            for (int a = 0; a < 6; a++) out_->box[24 * (size_t)idx + 6 * i + a] = box[a];
+        }
+        return idx;
+    }
+    int need4(int node) const {
+        int k = 0, deepest = 0;
+        for (int i = 0; i < 4; i++) {
+            const int32_t c = out_->child[4 * (size_t)node + i];
+            if (c == EMPTY) continue;
+            k++;
+            if (c >= 0) deepest = std::max(deepest, need4(c));
+        }
+        return std::max(0, k - 1) + deepest;
+    }
+};
+
+inline Bvh4 collapse_bvh4(const Bvh& b, int budget) { return Bvh4Collapser(b, budget).run(); }
+
 inline Bvh build_bvh(const std::vector<Aabb>& boxes, int max_leaf, int max_depth) {
     Bvh b = BvhBuilder(boxes, max_leaf, false).build();
     if (b.depth > max_depth) b = BvhBuilder(boxes, max_leaf, true).build();

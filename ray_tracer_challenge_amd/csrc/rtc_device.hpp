@@ -42,6 +42,12 @@
 #ifndef RTC_WAVES_F32
 #define RTC_WAVES_F32 4
 #endif
+#ifndef RTC_CSG_SLOTS
+#define RTC_CSG_SLOTS 0       // development (round 3, the CSG-variant fault): 1 = the CSG variants store per-wave ray count slots too
+#endif
+#ifndef RTC_BVH4_SORT_ANYHIT
+#define RTC_BVH4_SORT_ANYHIT 0   // development: 1 = shadow rays and container passes sort the children of a four-wide node like nearest-hit queries do
+#endif
 #ifndef RTC_BVH_STACK
 #define RTC_BVH_STACK 32      // per-lane traversal stack entries, in LDS
 #endif
@@ -123,6 +129,11 @@ template <class R> __device__ __forceinline__ V3<R> xtvector(const R* __restrict
 // device scene (struct of device pointers; one instance per precision)
 // ------------------------------------------------------------------------------------------
 struct alignas(64) BvhNode { float box[12]; int32_t child[2]; int32_t pad[2]; };
+// the triangle BVH's four-wide form (rtc_bvh.hpp, collapse_bvh4): four child boxes (lo xyz, hi xyz each, padded fp32) and four
+// child references in one 128-byte record = one L2 line per visit
+// src[k]: where child k's box lives in the binary tree the wide one was collapsed from, (binary node << 1) | side, -1 = none
+// (refits recompute the binary tree's boxes and copy them over, bvh4_refresh_kernel)
+struct alignas(128) BvhNode4 { float box[24]; int32_t child[4]; int32_t src[4]; };
 
 template <class R> struct DScene {
     int32_t n_leaves;
@@ -141,6 +152,7 @@ template <class R> struct DScene {
     float far_origin;              // 2 x the largest coordinate of any box: a ray that starts beyond it is re-based (traverse_bvh)
     int32_t n_tnodes;
     const BvhNode* tnodes;
+    const BvhNode4* tnodes4;       // the same tree four-wide: what rays walk (tnodes is what builds and refits work on)
     const R* tb_geom;              // [n_tris][12] tri_geom rows in BVH leaf order
     const int32_t* tb_leaf;        // [n_tris] leaf id, bit 31 set = does not cast shadows
     int32_t n_unbounded; const int32_t* unbounded_prims;
@@ -173,6 +185,7 @@ struct DFrame {
     // sum_rays_kernel adds them to `rays` after the launch.  NULL: every workgroup adds its counts to `rays` itself (40 000
     // atomics on one cache line per 1080p frame, which the memory side serialises: 25 us of a 0.2 ... 0.6 ms frame).
     unsigned long long* work;
+    int32_t n_slots;             // how many waves `work` has a slot for, when it holds slots (a wave beyond them adds its counts with atomics)
     int32_t max_depth;
     uint64_t seed;
     // Launch order of the pixel kernels: unit = 64 work items = one 8x8 pixel block.  The k-th wave of the
@@ -521,12 +534,12 @@ struct PrimCode {
 
 // Visitor V: bool prim(code) -> true = stop the traversal; R limit() = current far bound.
 // Boxes are visited when their slab interval overlaps (tlo, limit()).
-// TRIS = false: the object BVH (leaves hold prim codes -> vis.prim); TRIS = true: the triangle
-// BVH (leaves are ranges of tb_* rows -> vis.tri).  Returns true if the visitor stopped it.
-template <class R, class V, bool TRIS>
+// The OBJECT BVH (binary; leaves hold prim codes -> vis.prim); the triangle BVH is walked four-wide, traverse_bvh4.
+// Returns true if the visitor stopped it.
+template <class R, class V>
 __device__ __forceinline__ bool traverse_bvh(const DScene<R>& S, const Ray<R>& ray, R tlo, V& vis, int* stack /* LDS, stride = threads per workgroup */) {
     constexpr int kStride = std::remove_reference_t<decltype(vis.cnt)>::kBlock;
-    const BvhNode* __restrict__ nodes = TRIS ? S.tnodes : S.nodes;
+    const BvhNode* __restrict__ nodes = S.nodes;
     // Box tests run in fp32 whatever R is: the boxes are padded outward by 2e-5 (relative, >= 2e-5
     // absolute) on the host, which covers rounding the ray to fp32, and the slab distances get a
     // 1e-5 relative slack before every comparison -- the test can only accept MORE than an exact
@@ -549,7 +562,7 @@ __device__ __forceinline__ bool traverse_bvh(const DScene<R>& S, const Ray<R>& r
     float ox = -(float)ray.o.x * ix, oy = -(float)ray.o.y * iy, oz = -(float)ray.o.z * iz;
     float tlo32 = (float)tlo;
     if (V::Cnt::kFar && fmaxf(fmaxf(fabsf((float)ray.o.x), fabsf((float)ray.o.y)), fabsf((float)ray.o.z)) > S.far_origin) {
-        const float* rb = TRIS ? S.tbox : S.obox;
+        const float* rb = S.obox;
         const float px = (float)ray.o.x, py = (float)ray.o.y, pz = (float)ray.o.z;
         const float x0 = (rb[0] - px) * ix, x1 = (rb[3] - px) * ix, y0 = (rb[1] - py) * iy, y1 = (rb[4] - py) * iy, z0 = (rb[2] - pz) * iz, z1 = (rb[5] - pz) * iz;
         float enter = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
@@ -613,10 +626,123 @@ __device__ __forceinline__ bool traverse_bvh(const DScene<R>& S, const Ray<R>& r
         } else {
             int code = ~node;
             int first = code >> 4, count = (code & 15) + 1;
-            bool uniform = false;
-            if (TRIS) uniform = __builtin_amdgcn_ballot_w64(code != __builtin_amdgcn_readfirstlane(code)) == 0ull;
             for (int i = 0; i < count; i++)
-                if (TRIS ? vis.tri(first + i, uniform) : vis.prim(S.bvh_prims[first + i])) return true;
+                if (vis.prim(S.bvh_prims[first + i])) return true;
+        }
+        if (sp == 0) return false;
+        sp--;
+        node = stack[sp * kStride];
+    }
+}
+
+// The triangle BVH in its four-wide form.  Same conservative fp32 slab test per child box as traverse_bvh; the children
+// that are hit are visited nearest first: their entry distances (clamped at 0, the child's slot in the two lowest mantissa
+// bits) are sorted as unsigned integers by a five-exchange network, the nearest is entered, the others are pushed farthest
+// first.  The order changes no result (every child that is hit is visited unless the limit has shrunk below its entry
+// distance by then -- the visitor's own comparison decides, as in the binary walk).
+template <class R, class V>
+__device__ __forceinline__ bool traverse_bvh4(const DScene<R>& S, const Ray<R>& ray, R tlo, V& vis, int* stack /* LDS, stride = threads per workgroup */) {
+    constexpr int kStride = std::remove_reference_t<decltype(vis.cnt)>::kBlock;
+    const BvhNode4* __restrict__ nodes = S.tnodes4;
+    float ix = 1.0f / (float)ray.d.x, iy = 1.0f / (float)ray.d.y, iz = 1.0f / (float)ray.d.z;
+    if (!(fabsf(ix) <= 1e30f)) ix = copysignf(1e30f, (float)ray.d.x);
+    if (!(fabsf(iy) <= 1e30f)) iy = copysignf(1e30f, (float)ray.d.y);
+    if (!(fabsf(iz) <= 1e30f)) iz = copysignf(1e30f, (float)ray.d.z);
+    float base32 = 0.0f, lim_pad = 0.0f;
+    float ox = -(float)ray.o.x * ix, oy = -(float)ray.o.y * iy, oz = -(float)ray.o.z * iz;
+    float tlo32 = (float)tlo;
+    if (V::Cnt::kFar && fmaxf(fmaxf(fabsf((float)ray.o.x), fabsf((float)ray.o.y)), fabsf((float)ray.o.z)) > S.far_origin) {      // see traverse_bvh
+        const float* rb = S.tbox;
+        const float px = (float)ray.o.x, py = (float)ray.o.y, pz = (float)ray.o.z;
+        const float x0 = (rb[0] - px) * ix, x1 = (rb[3] - px) * ix, y0 = (rb[1] - py) * iy, y1 = (rb[4] - py) * iy, z0 = (rb[2] - pz) * iz, z1 = (rb[5] - pz) * iz;
+        float enter = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
+        enter -= 1e-3f * fabsf(enter) + 1e-3f;
+        enter = fmaxf(enter, (float)tlo);
+        if (fabsf(enter) < 1e30f) {
+            const R base = R(enter);
+            base32 = enter; lim_pad = 2.4e-7f * fabsf(enter);
+            ox = -(float)(ray.o.x + ray.d.x * base) * ix; oy = -(float)(ray.o.y + ray.d.y * base) * iy; oz = -(float)(ray.o.z + ray.d.z * base) * iz;
+            tlo32 = (float)(tlo - base);
+        }
+    }
+    int sp = 0;
+    int node = 0;
+    while (true) {
+        if (node >= 0) {
+            vis.cnt.work(W_NODE);
+            float b[24];
+            int c[4];
+            const int node0 = __builtin_amdgcn_readfirstlane(node);
+            if (__builtin_amdgcn_ballot_w64(node != node0) == 0ull) {
+                // every active lane at the same node: the record comes through the scalar unit (28 of its 32 dwords)
+                typedef float f16v __attribute__((ext_vector_type(16)));
+                typedef float f8v __attribute__((ext_vector_type(8)));
+                typedef int i4v __attribute__((ext_vector_type(4)));
+                f16v r0; f8v r1; i4v r2;
+                const BvhNode4* p0 = uniform_ptr(nodes + node0);
+                asm volatile("s_load_dwordx16 %0, %3, 0x0\n\ts_load_dwordx8 %1, %3, 0x40\n\ts_load_dwordx4 %2, %3, 0x60\n\ts_waitcnt lgkmcnt(0)"
+                             : "=&s"(r0), "=&s"(r1), "=&s"(r2) : "s"(p0) : "memory");
+#pragma unroll
+                for (int k = 0; k < 16; k++) b[k] = r0[k];
+#pragma unroll
+                for (int k = 0; k < 8; k++) b[16 + k] = r1[k];
+                c[0] = r2[0]; c[1] = r2[1]; c[2] = r2[2]; c[3] = r2[3];
+            } else {
+                const float4* q = reinterpret_cast<const float4*>(nodes + node);
+#pragma unroll
+                for (int k = 0; k < 6; k++) { const float4 v = q[k]; b[4 * k] = v.x; b[4 * k + 1] = v.y; b[4 * k + 2] = v.z; b[4 * k + 3] = v.w; }
+                const float4 v = q[6];
+                c[0] = __float_as_int(v.x); c[1] = __float_as_int(v.y); c[2] = __float_as_int(v.z); c[3] = __float_as_int(v.w);
+            }
+            float lim = (float)vis.limit();
+            if (V::Cnt::kFar) lim -= base32;
+            lim += fabsf(lim) * 1e-6f;
+            if (V::Cnt::kFar) lim += lim_pad;
+            unsigned int key[4];
+            bool hit[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const float* lo = b + 6 * k; const float* hi = lo + 3;
+                float x0 = fmaf(lo[0], ix, ox), x1 = fmaf(hi[0], ix, ox);
+                float y0 = fmaf(lo[1], iy, oy), y1 = fmaf(hi[1], iy, oy);
+                float z0 = fmaf(lo[2], iz, oz), z1 = fmaf(hi[2], iz, oz);
+                float n = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
+                float f = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
+                n -= fabsf(n) * 1e-5f;
+                f += fabsf(f) * 1e-5f;
+                hit[k] = c[k] != RTC_EMPTY_CHILD && n <= f && f >= tlo32 && n <= lim;
+                key[k] = hit[k] ? ((__float_as_uint(fmaxf(n, 0.0f)) & ~3u) | (unsigned)k) : 0xFFFFFFFFu;
+            }
+            if (!RTC_BVH4_SORT_ANYHIT && V::kUnordered) {
+                // any-hit queries and passes with a fixed far bound need no order among the children: one that is hit is entered, the others pushed
+                int next = RTC_EMPTY_CHILD;
+#pragma unroll
+                for (int k = 3; k >= 0; k--)
+                    if (hit[k]) {
+                        if (next != RTC_EMPTY_CHILD) { stack[sp * kStride] = next; sp++; }
+                        next = c[k];
+                    }
+                if (next != RTC_EMPTY_CHILD) { node = next; continue; }
+            } else {
+#define RTC_CE(i, j) { const unsigned int lo_ = key[i] < key[j] ? key[i] : key[j], hi_ = key[i] < key[j] ? key[j] : key[i]; key[i] = lo_; key[j] = hi_; }
+                RTC_CE(0, 1) RTC_CE(2, 3) RTC_CE(0, 2) RTC_CE(1, 3) RTC_CE(1, 2)
+#undef RTC_CE
+#define RTC_PICK(kk) (((kk) & 3u) == 0u ? c[0] : ((kk) & 3u) == 1u ? c[1] : ((kk) & 3u) == 2u ? c[2] : c[3])
+                if (key[0] != 0xFFFFFFFFu) {
+                    if (key[3] != 0xFFFFFFFFu) { stack[sp * kStride] = RTC_PICK(key[3]); sp++; }
+                    if (key[2] != 0xFFFFFFFFu) { stack[sp * kStride] = RTC_PICK(key[2]); sp++; }
+                    if (key[1] != 0xFFFFFFFFu) { stack[sp * kStride] = RTC_PICK(key[1]); sp++; }
+                    node = RTC_PICK(key[0]);
+                    continue;
+                }
+            }
+#undef RTC_PICK
+        } else {
+            int code = ~node;
+            int first = code >> 4, count = (code & 15) + 1;
+            const bool uniform = __builtin_amdgcn_ballot_w64(code != __builtin_amdgcn_readfirstlane(code)) == 0ull;
+            for (int i = 0; i < count; i++)
+                if (vis.tri(first + i, uniform)) return true;
         }
         if (sp == 0) return false;
         sp--;
@@ -659,10 +785,10 @@ template <class R, class V> __device__ __forceinline__ void traverse_objects(con
             if (vis.prim(S.bvh_prims[i])) return;
         return;
     }
-    if (S.n_bvh_nodes > 0) traverse_bvh<R, V, false>(S, ray, tlo, vis, stack);
+    if (S.n_bvh_nodes > 0) traverse_bvh<R, V>(S, ray, tlo, vis, stack);
 }
 template <class R, class V> __device__ __forceinline__ void traverse_tris(const DScene<R>& S, const Ray<R>& ray, R tlo, V& vis, int* stack) {
-    if (S.n_tnodes > 0) traverse_bvh<R, V, true>(S, ray, tlo, vis, stack);
+    if (S.n_tnodes > 0) traverse_bvh4<R, V>(S, ray, tlo, vis, stack);
 }
 template <class R, class V> __device__ __forceinline__ void traverse(const DScene<R>& S, const Ray<R>& ray, R tlo, V& vis, int* stack) {
     traverse_objects(S, ray, tlo, vis, stack);
@@ -676,6 +802,7 @@ template <class R, class CNT> struct NearestVisitor {
     R best; int leaf; R u, v;
     __device__ __forceinline__ NearestVisitor(const DScene<R>& s, const Ray<R>& r, CNT& c) : S(s), ray(r), cnt(c), best(inf_<R>()), leaf(-1), u(0), v(0) {}
     static constexpr bool kFlatRootBox = true;
+    static constexpr bool kUnordered = false;
     __device__ __forceinline__ R limit() const { return best; }
     __device__ __forceinline__ bool done() const { return false; }
     __device__ __forceinline__ bool tri(int pos, bool uniform = false) {
@@ -725,6 +852,7 @@ template <class R, class CNT> struct ShadowVisitor {
     const DScene<R>& S; const Ray<R>& ray; CNT& cnt; R dist; bool shadowed;
     __device__ __forceinline__ ShadowVisitor(const DScene<R>& s, const Ray<R>& r, R d, CNT& c) : S(s), ray(r), cnt(c), dist(d), shadowed(false) {}
     static constexpr bool kFlatRootBox = false;    // shadow rays start on the objects: most of them are inside the box anyway
+    static constexpr bool kUnordered = true;
     __device__ __forceinline__ R limit() const { return dist; }
     __device__ __forceinline__ bool done() const { return shadowed; }
     __device__ __forceinline__ bool tri(int pos, bool uniform = false) {
@@ -781,6 +909,7 @@ template <class R, class CNT> struct ContainerVisitor {
     __device__ __forceinline__ ContainerVisitor(const DScene<R>& s, const Ray<R>& r, R th, int xl, CNT& c)
         : S(s), ray(r), cnt(c), t_hit(th), x_leaf(xl), x_odd(false), x_last(-inf_<R>()), y_leaf(-1), y_last(-inf_<R>()) {}
     static constexpr bool kFlatRootBox = true;
+    static constexpr bool kUnordered = true;          // the far bound is fixed and every leaf in range is visited: no order among children needed
     __device__ __forceinline__ R limit() const { return t_hit; }
     __device__ __forceinline__ bool done() const { return false; }
     __device__ __forceinline__ bool tri(int pos, bool = false) {
@@ -1466,7 +1595,7 @@ template <class R> __device__ __forceinline__ Ray<R> ray_for_pixel(const DCamera
 template <bool PROF, bool CSG, bool FAR, bool STREAM, bool REPL>
 __device__ __forceinline__ void flush_counters(Counters<PROF, CSG, FAR, STREAM, REPL>& cnt, const DFrame& F, unsigned int* red /* LDS, >= 5 * waves per workgroup */) {
     constexpr int kWaves = Counters<PROF, CSG, FAR, STREAM, REPL>::kBlock / 64;
-    if (!PROF && !CSG && F.rays && F.work) {          // per-wave slots (DFrame::work; the host sets it for the variants without CSG only)
+    if (!PROF && (!CSG || RTC_CSG_SLOTS) && F.rays && F.work) {          // per-wave slots (DFrame::work)
         uint32_t* parts = reinterpret_cast<uint32_t*>(F.work);
         const int ln = threadIdx.x & 63;
         unsigned int mine = 0;
@@ -1476,7 +1605,9 @@ __device__ __forceinline__ void flush_counters(Counters<PROF, CSG, FAR, STREAM, 
             v = __builtin_amdgcn_readfirstlane(v);
             if (ln == k) mine = v;
         }
-        if (ln < 8) parts[((size_t)blockIdx.x * kWaves + (threadIdx.x >> 6)) * 8 + ln] = mine;      // one 32-byte store per wave
+        const size_t slot = (size_t)blockIdx.x * kWaves + (threadIdx.x >> 6);
+        if (slot < (size_t)F.n_slots) { if (ln < 8) parts[slot * 8 + ln] = mine; }      // one 32-byte store per wave
+        else if (ln < 5 && mine) atomicAdd(F.rays + (ln < 4 ? ln : 12), (unsigned long long)mine);      // no slot for this wave (never, by the host's arithmetic)
     } else if (F.rays) {
         __syncthreads();
         for (int k = 0; k < 5; k++) {

@@ -199,4 +199,104 @@ __global__ void bvh_refit_kernel(int n_nodes, BvhNode* nodes, const int32_t* par
     }
 }
 
+// ---- the four-wide form rays walk (BvhNode4), kept in step with the binary tree builds and refits work on ----
+
+// after a refit of the binary tree: every wide child box copied from where it lives in the binary tree (BvhNode4::src)
+__global__ void bvh4_refresh_kernel(int n4, BvhNode4* nodes4, const BvhNode* nodes2) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    for (int k = 0; k < 4; k++) {
+        const int32_t src = nodes4[i].src[k];
+        if (src < 0) continue;
+        const float* from = nodes2[src >> 1].box + 6 * (src & 1);
+        for (int a = 0; a < 6; a++) nodes4[i].box[6 * k + a] = from[a];
+    }
+}
+
+// height[p] of every inner node of the GPU-built binary tree = the pending stack entries a binary walk can have at and
+// below it (1 + the larger of its children's; leaves 0): every leaf climbs, raising the heights on its way, and stops
+// where somebody else has already reported at least as much (who then carries at least that much further up)
+__global__ void lbvh_height_kernel(int n_leaves, const int32_t* parent_inner, const int32_t* parent_leaf, int32_t* height) {
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_leaves) return;
+    int level = 1;
+    for (int32_t link = parent_leaf[j]; link >= 0 && level < 4096; link = parent_inner[link >> 1], level++)
+        if (atomicMax(height + (link >> 1), level) >= level) return;
+}
+
+// What a wide node at binary node `a` with `budget` pending entries to spare takes in: both children replaced by their own
+// children (four slots) if everything below those still fits budget - 3, else the child with the larger box alone (three
+// slots, budget - 2) if that fits, else the other, else the binary node as it is (two slots, budget - 1: always fits, since
+// height[a] <= budget).  The same invariant as the host's collapse_bvh4 (rtc_bvh.hpp): need4 <= budget by construction.
+struct Collapse4 { bool expand[2]; int k; };
+__device__ __forceinline__ Collapse4 lbvh_collapse_decision(const BvhNode* nodes2, const int32_t* height, int a, int budget) {
+    const int32_t c[2] = {nodes2[a].child[0], nodes2[a].child[1]};
+    int need[2], gneed[2];
+    float area[2];
+    for (int s = 0; s < 2; s++) {
+        need[s] = c[s] >= 0 ? height[c[s]] : 0;
+        gneed[s] = 0;
+        if (c[s] >= 0)
+            for (int q = 0; q < 2; q++) { const int32_t g = nodes2[c[s]].child[q]; if (g >= 0) gneed[s] = max(gneed[s], height[g]); }
+        const float* b = nodes2[a].box + 6 * s;
+        const float dx = b[3] - b[0], dy = b[4] - b[1], dz = b[5] - b[2];
+        area[s] = (dx < 0.0f || dy < 0.0f || dz < 0.0f) ? 0.0f : dx * dy + dy * dz + dz * dx;
+    }
+    Collapse4 d;
+    d.expand[0] = d.expand[1] = false; d.k = 2;
+    if (c[0] >= 0 && c[1] >= 0 && max(gneed[0], gneed[1]) <= budget - 3) { d.expand[0] = d.expand[1] = true; d.k = 4; return d; }
+    const bool ok0 = c[0] >= 0 && gneed[0] <= budget - 2 && need[1] <= budget - 2;
+    const bool ok1 = c[1] >= 0 && gneed[1] <= budget - 2 && need[0] <= budget - 2;
+    if (ok0 && (!ok1 || area[0] >= area[1])) { d.expand[0] = true; d.k = 3; }
+    else if (ok1) { d.expand[1] = true; d.k = 3; }
+    return d;
+}
+
+// The GPU-built binary tree collapsed into wide nodes, one thread per binary inner node.  Wide node i sits at binary node
+// i's index (nodes that were taken into their parent's record leave a hole: an all-empty record nothing refers to).  Whether
+// a node keeps a record of its own, and with what budget, follows from its ancestors' decisions: the thread replays them
+// from the root down along its own path (<= 31 steps).
+__global__ void lbvh_collapse4_kernel(int n_inner, const BvhNode* nodes2, const int32_t* parent_inner, const int32_t* height, int budget, BvhNode4* nodes4) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_inner) return;
+    int path[64];
+    int len = 0;
+    for (int a = i; a >= 0 && len < 64; a = parent_inner[a] >= 0 ? (parent_inner[a] >> 1) : -1) path[len++] = a;      // i ... root
+    BvhNode4 out;
+    for (int k = 0; k < 4; k++) {
+        out.child[k] = RTC_EMPTY_CHILD; out.src[k] = -1;
+        for (int a = 0; a < 3; a++) { out.box[6 * k + a] = 3.0e38f; out.box[6 * k + 3 + a] = -3.0e38f; }
+    }
+    int t = len - 1, B = budget;
+    bool kept = len < 64;
+    Collapse4 d = {{false, false}, 2};
+    while (kept) {
+        d = lbvh_collapse_decision(nodes2, height, path[t], B);
+        if (t == 0) break;                                               // path[0] = i keeps a record, with decision d
+        const int side = nodes2[path[t]].child[0] == path[t - 1] ? 0 : 1;
+        B -= d.k - 1;
+        if (d.expand[side]) {
+            if (t == 1) kept = false;                                    // i itself went into its parent's record
+            t -= 2;
+        } else t -= 1;
+    }
+    if (kept) {
+        int k = 0;
+        for (int s = 0; s < 2; s++) {
+            const int32_t c = nodes2[i].child[s];
+            if (d.expand[s]) {
+                for (int q = 0; q < 2; q++, k++) {
+                    out.child[k] = nodes2[c].child[q]; out.src[k] = (c << 1) | q;
+                    for (int a = 0; a < 6; a++) out.box[6 * k + a] = nodes2[c].box[6 * q + a];
+                }
+            } else {
+                out.child[k] = c; out.src[k] = c == RTC_EMPTY_CHILD ? -1 : ((i << 1) | s);
+                for (int a = 0; a < 6; a++) out.box[6 * k + a] = nodes2[i].box[6 * s + a];
+                k++;
+            }
+        }
+    }
+    nodes4[i] = out;
+}
+
 }  // namespace rtc
