@@ -918,7 +918,7 @@ void launch_trace(const rtc_scene* scene, const rtc_camera* cam, const rtc::DFra
                   hipStream_t stream, bool two_waves = false) {
     const bool csg = scene->has_csg;
     // `grid` counts RTC_BLOCK-thread blocks (4 entries of the launch order each); the variants without CSG run one entry per workgroup
-    const dim3 block(csg ? RTC_BLOCK : RTC_BLOCK_PLAIN);
+    const dim3 block(csg ? RTC_BLOCK_CSG : RTC_BLOCK_PLAIN);
     grid = dim3(grid.x * (RTC_BLOCK / block.x));
     // a camera farther out than the boxes' padding covers (DScene::far_origin) gets the variants that re-base rays
     const double far_origin = scene->d64.far_origin;
@@ -937,9 +937,8 @@ void launch_trace(const rtc_scene* scene, const rtc_camera* cam, const rtc::DFra
 #define RTC_LAUNCH_CSG12(R, SC) do { if (!scene->has_csg_stream) RTC_LAUNCH_FAR(R, 1, SC); else RTC_LAUNCH_FAR(R, 2, SC); } while (0)
 #endif
     if (precision == 64) {
-        // without CSG: the variants of rtc_trace_f64.hip (built without machine LICM, which parks hoisted fp64 constants in scratch)
-        if (!csg) rtc::launch_trace_f64_plain(prof, far_cam, repl, two_waves, grid, stream, scene->d64, make_camera<double>(*cam), F, eps, eps_rel);
-        else RTC_LAUNCH_CSG12(double, scene->d64);
+        // the variants of rtc_trace_f64.hip (built without machine LICM, which parks hoisted fp64 constants in scratch)
+        rtc::launch_trace_f64(!csg ? 0 : scene->has_csg_stream ? 2 : 1, prof, far_cam, repl, two_waves, grid, stream, scene->d64, make_camera<double>(*cam), F, eps, eps_rel);
     } else {
         if (!csg) RTC_LAUNCH_FAR(float, 0, scene->d32); else RTC_LAUNCH_CSG12(float, scene->d32);
     }
@@ -1071,6 +1070,8 @@ int launch(rtc_scene* scene, const rtc_camera* cam, const rtc_render_opts* opts,
     // to clear) -- in the variants without CSG, which count no work
     uint32_t* ray_parts = (ws && want_parts) ? ws->ray_parts : nullptr;
     if (ray_parts) { F.work = reinterpret_cast<unsigned long long*>(ray_parts); F.n_slots = (int32_t)n_entries; }
+    if (ray_parts && (long long)grid.x * (RTC_BLOCK / 64) > n_entries)      // every wave of the grid has a slot (the kernel's own guard never fires)
+        return fail(RTC_ERR_HIP, "internal: %lld waves for %lld ray count slots", (long long)grid.x * (RTC_BLOCK / 64), n_entries);
     if (timing >= 0) HIP_TRY(hipEventRecord(ws->tune_ev[timing], stream));
     launch_trace(scene, cam, F, grid, precision, work_dev != nullptr, eps, eps_rel, stream, two_waves);
     if (int rc = debug_sync(stream, "trace_kernel", grid.x, F)) return rc;

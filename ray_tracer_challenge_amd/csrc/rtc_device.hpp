@@ -42,8 +42,15 @@
 #ifndef RTC_WAVES_F32
 #define RTC_WAVES_F32 4
 #endif
+// The variants for scenes with CSG objects or perturbed patterns ran 256-thread workgroups that counted rays through workgroup
+// atomics until round 3 (a first attempt to give them the per-wave slots had faulted in round 2 and was shelved; rebuilt in
+// round 3 with a bounds guard on the slot index and a host-side wait after every kernel, the same frames ran clean --
+// DESIGN.md).  Development overrides to get the old form back: -DRTC_CSG_SLOTS=0 -DRTC_BLOCK_CSG=256.
 #ifndef RTC_CSG_SLOTS
-#define RTC_CSG_SLOTS 0       // development (round 3, the CSG-variant fault): 1 = the CSG variants store per-wave ray count slots too
+#define RTC_CSG_SLOTS 1
+#endif
+#ifndef RTC_BLOCK_CSG
+#define RTC_BLOCK_CSG RTC_BLOCK_PLAIN
 #endif
 #ifndef RTC_BVH4_SORT_ANYHIT
 #define RTC_BVH4_SORT_ANYHIT 0   // development: 1 = shadow rays and container passes sort the children of a four-wide node like nearest-hit queries do
@@ -243,7 +250,7 @@ template <bool PROF, bool CSG = true, bool FAR = false, bool STREAM = false, boo
     static constexpr bool kFar = FAR;
     static constexpr bool kStream = CSG && STREAM;
     static constexpr bool kReplicas = REPL;
-    static constexpr int kBlock = CSG ? RTC_BLOCK : RTC_BLOCK_PLAIN;      // threads per workgroup = stride of the per-lane traversal stack in LDS
+    static constexpr int kBlock = CSG ? RTC_BLOCK_CSG : RTC_BLOCK_PLAIN;      // threads per workgroup = stride of the per-lane traversal stack in LDS
     int rep, nrep;             // this lane is replica `rep` of `nrep` of its pixel (wave_unit); nrep is the same for the whole wave
     unsigned int c[5];         // primary, shadow, reflection, refraction rays traced; shadow rays not traced (light behind the surface)
     unsigned int w[PROF ? W_COUNT : 1];

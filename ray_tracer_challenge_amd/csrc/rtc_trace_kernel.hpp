@@ -1,6 +1,6 @@
 // rtc_trace_kernel.hpp -- the trace kernel template, shared by the two translation units of librtc_hip.so:
-// rtc_api.hip instantiates the fp32 variants and every CSG variant, rtc_trace_f64.hip the fp64 variants without CSG
-// (compiled with other optimiser settings: see the Makefile).
+// rtc_api.hip instantiates the fp32 variants, rtc_trace_f64.hip the fp64 variants (compiled with other optimiser settings:
+// see the Makefile).
 #pragma once
 #include "rtc_device.hpp"
 
@@ -14,7 +14,7 @@ namespace rtc {
 // times both for every view.
 #define RTC_WAVES_OF(R, CSG) ((CSG) ? 2 : sizeof(R) == 8 ? RTC_WAVES_F64 : RTC_WAVES_F32)
 template <class R, bool PROF, int CSG, bool FAR, bool REPL, int WAVES>
-__global__ __launch_bounds__((CSG > 0) ? RTC_BLOCK : RTC_BLOCK_PLAIN, WAVES) void trace_kernel(rtc::DScene<R> S, rtc::DCamera<R> cam, rtc::DFrame F, R shade_eps, R shade_eps_rel) {
+__global__ __launch_bounds__((CSG > 0) ? RTC_BLOCK_CSG : RTC_BLOCK_PLAIN, WAVES) void trace_kernel(rtc::DScene<R> S, rtc::DCamera<R> cam, rtc::DFrame F, R shade_eps, R shade_eps_rel) {
     using CNT = rtc::Counters<PROF, (CSG > 0), FAR, (CSG == 2), REPL>;
     __shared__ int s_stack[RTC_BVH_STACK * CNT::kBlock];
     int* stack = s_stack + threadIdx.x;
@@ -51,9 +51,9 @@ __global__ __launch_bounds__((CSG > 0) ? RTC_BLOCK : RTC_BLOCK_PLAIN, WAVES) voi
     rtc::flush_counters(cnt, F, reinterpret_cast<unsigned int*>(s_stack));
 }
 
-// the fp64 variants without CSG, launched from the translation unit that holds them (rtc_trace_f64.hip); `grid` counts
-// workgroups of RTC_BLOCK_PLAIN threads
-void launch_trace_f64_plain(bool prof, bool far_cam, bool repl, bool two_waves, dim3 grid, hipStream_t stream, const DScene<double>& S,
-                            const DCamera<double>& cam, const DFrame& F, double eps, double eps_rel);
+// the fp64 variants, launched from the translation unit that holds them (rtc_trace_f64.hip); csg = 0, 1, 2 as the template's
+// CSG; `grid` counts workgroups of RTC_BLOCK_PLAIN (csg = 0) / RTC_BLOCK_CSG threads
+void launch_trace_f64(int csg, bool prof, bool far_cam, bool repl, bool two_waves, dim3 grid, hipStream_t stream, const DScene<double>& S,
+                      const DCamera<double>& cam, const DFrame& F, double eps, double eps_rel);
 
 }  // namespace rtc
