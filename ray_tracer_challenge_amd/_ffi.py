@@ -296,9 +296,9 @@ class Scene(object):
         return (a[:n.value].tobytes() if clamped else None, b[:n.value].tobytes() if scaled else None)
 
     def render_tiles(self, cam, tile_ids, precision="fp64", max_depth=5, tile_size=32, want_ids=False, stats=None,
-                     shade_eps=0.0, seed=0, feedback=True):
+                     shade_eps=0.0, seed=0, feedback=True, count_work=False):
         """Compact tiles -> (rgb (n, T, T, 3) [slot][ty][tx], ids (n, T, T) or None)."""
-        c, o, st = make_camera(cam), make_opts(precision, max_depth, tile_size, shade_eps, seed, feedback=feedback), Stats()
+        c, o, st = make_camera(cam), make_opts(precision, max_depth, tile_size, shade_eps, seed, count_work, feedback=feedback), Stats()
         tiles = np.ascontiguousarray(tile_ids, dtype=np.int32)
         n, T = tiles.size, tile_size
         rgb = _pinned.empty((n, T, T, 3), np.float64)

@@ -42,7 +42,7 @@ __global__ __launch_bounds__((CSG > 0) ? RTC_BLOCK_CSG : RTC_BLOCK_PLAIN, WAVES)
             cnt.c[0] = 1;
             F.rgb[3 * o] = (double)c.x; F.rgb[3 * o + 1] = (double)c.y; F.rgb[3 * o + 2] = (double)c.z;
             if (F.hit_id) F.hit_id[o] = hit_leaf;
-        } else cnt.c[2] = cnt.c[3] = 0;               // replicas trace the same camera, reflection and refraction rays: counted once
+        }                                             // (replicas: reflection / refraction rays are counted once, trace_pixel sees to it)
     }
     if (F.cost && unit >= 0 && lane == 0) {
         long long dt = (long long)wall_clock64() - t_start;
