@@ -62,9 +62,13 @@ class _Compiler(object):
     def __init__(self):
         self.leaf_kind, self.leaf_xform, self.leaf_material, self.leaf_tri = [], [], [], []
         self.leaf_minmax, self.leaf_closed, self.leaf_objects = [], [], []
-        self.leaf_lo, self.leaf_hi = [], []          # world AABB per leaf (triangles filled in bulk later)
+        self.leaf_lo = []                            # (leaf, lo, hi): world AABB of the analytic leaves that have a finite one
         self.xforms, self._xform_of = [], {}
         self.tri_rows, self.tri_xform, self.tri_leaf, self.tri_flat = [], [], [], []
+        self.tri_single = []                         # which triangle rows came one by one (tri_rows, tri_xform, tri_leaf, tri_flat hold theirs, in this order)
+        self.leaf_single = []                        # likewise for leaves: the leaf ids the per-leaf lists above are for
+        self.runs = []                               # (first leaf, count, xform row, material, first triangle row, (n, 18) array, in_csg): loader-made runs, flattened in bulk
+        self.n_leaves = self.n_tris = 0
         self.items, self.unbounded = [], []          # (kind, leaf or csg root)
         self.csg_roots, self.csg_nodes, self.csg_bbox = [], [], []
         self.materials, self._mat_of = [], {}
@@ -106,33 +110,52 @@ class _Compiler(object):
         inv = self._inverse(obj.transform)
         m = inv if m_parent is None else (m_parent if inv is self._ident else inv @ m_parent)
         if name == "Group":
-            for c in list(obj.children):
+            kids = list(obj.children)
+            at = 0
+            for run in sorted(getattr(obj, "triangle_runs", None) or [], key=lambda r: r.start):
+                if run.start < at or not run.still_valid(kids):
+                    continue                                   # not what the loader made any more: the objects are read one by one
+                for c in kids[at:run.start]:
+                    self.shape(c, m, in_csg)
+                self._triangle_run(run, kids, m, in_csg)
+                at = run.start + run.count
+            for c in kids[at:]:
                 self.shape(c, m, in_csg)
         elif name == "CSG":
             if in_csg:
                 self._csg_node(obj, m)
             else:
-                first_node, first_leaf = len(self.csg_nodes), len(self.leaf_kind)
+                first_node, first_leaf = len(self.csg_nodes), self.n_leaves
                 self._csg_node(obj, m)
-                self.csg_roots.append([first_node, len(self.csg_nodes) - first_node, first_leaf, len(self.leaf_kind)])
+                self.csg_roots.append([first_node, len(self.csg_nodes) - first_node, first_leaf, self.n_leaves])
         elif name in _KIND:
             self._leaf(obj, name, m, in_csg)
         else:
             raise ValueError("unknown shape class " + name)
 
     def _csg_node(self, obj, m):
-        l0 = len(self.leaf_kind)
+        l0 = self.n_leaves
         self.shape(obj.left, m, True)
-        l1 = len(self.leaf_kind)
+        l1 = self.n_leaves
         self.shape(obj.right, m, True)
-        l2 = len(self.leaf_kind)
+        l2 = self.n_leaves
         b = obj.bounds()
         self.csg_nodes.append([_CSG_OP[_cname(obj.op)], l0, l1, l2, self._xform(m)])
         self.csg_bbox.append(list(_a(b.min, 3)) + list(_a(b.max, 3)))
 
+    def _triangle_run(self, run, kids, m, in_csg):
+        """run.count SmoothTriangle leaves (identity transforms, one material) from the loader's own block of vertex data."""
+        n = run.count
+        self.runs.append((self.n_leaves, n, self._xform(m), self._material(run.material), self.n_tris, run.rows, in_csg))
+        self.leaf_objects.extend(kids[run.start:run.start + n])
+        self.n_leaves += n
+        self.n_tris += n
+
     def _leaf(self, obj, name, m, in_csg):
         kind = _KIND[name]
-        leaf = len(self.leaf_kind)
+        leaf = self.n_leaves
+        self.n_leaves += 1
+        self.leaf_single.append(leaf)
         mat = self._material(obj.material)
         self.leaf_kind.append(kind)
         self.leaf_xform.append(self._xform(m))
@@ -140,7 +163,7 @@ class _Compiler(object):
         self.leaf_objects.append(obj)
         lo, hi, minmax, closed = None, None, (0.0, 0.0), 0
         if kind == K_TRIANGLE:
-            self.leaf_tri.append(len(self.tri_rows))
+            self.leaf_tri.append(self.n_tris)
             flat = name == "Triangle"
             # the raw vertex (and normal) arrays; stacked in bulk by finish()
             p1, p2, p3 = obj.p1, obj.p2, obj.p3
@@ -150,6 +173,8 @@ class _Compiler(object):
                 n1, n2, n3 = obj.n1, obj.n2, obj.n3
                 self.tri_rows.append((getattr(p1, "arr", p1), getattr(p2, "arr", p2), getattr(p3, "arr", p3),
                                       getattr(n1, "arr", n1), getattr(n2, "arr", n2), getattr(n3, "arr", n3)))
+            self.tri_single.append(self.n_tris)
+            self.n_tris += 1
             self.tri_xform.append(self.leaf_xform[-1])
             self.tri_leaf.append(leaf)
             self.tri_flat.append(flat)
@@ -161,8 +186,8 @@ class _Compiler(object):
             lo, hi = self._analytic_bounds(kind, minmax, m, closed)
         self.leaf_minmax.append(minmax)
         self.leaf_closed.append(closed)
-        self.leaf_lo.append(lo)
-        self.leaf_hi.append(hi)
+        if lo is not None:
+            self.leaf_lo.append((leaf, lo, hi))        # analytic leaves with a finite box (triangles get theirs in bulk, finish())
         if not in_csg:
             (self.items if (kind == K_TRIANGLE or lo is not None) else self.unbounded).append((kind, leaf))
 
@@ -283,30 +308,48 @@ class _Compiler(object):
         f64, i32 = np.float64, np.int32
         cs = CompiledScene()
         A, C = cs.arrays, cs.counts
-        n_leaves = len(self.leaf_kind)
+        n_leaves, n_tris = self.n_leaves, self.n_tris
         xf = np.array(self.xforms, f64).reshape(-1, 4, 4) if self.xforms else np.zeros((0, 4, 4))
         mat_shadow = np.array([m[1] for m in self.materials] or [1], i32)
-        leaf_material = np.array(self.leaf_material, i32).reshape(-1)
+
+        # per-leaf and per-triangle tables: the leaves that were walked one by one (the lists) and the loader-made runs (slices)
+        ls, ts = np.array(self.leaf_single, np.int64), np.array(self.tri_single, np.int64)
+
+        def table(n, dt, at, singles, width=None):
+            out = np.zeros(n if width is None else (n, width), dt)
+            if len(at):
+                out[at] = np.array(singles, dt).reshape((-1,) if width is None else (-1, width))
+            return out
+        leaf_kind, leaf_xform = table(n_leaves, i32, ls, self.leaf_kind), table(n_leaves, i32, ls, self.leaf_xform)
+        leaf_material, leaf_tri = table(n_leaves, i32, ls, self.leaf_material), table(n_leaves, i32, ls, self.leaf_tri)
+        leaf_minmax, leaf_closed = table(n_leaves, f64, ls, self.leaf_minmax, 2), table(n_leaves, i32, ls, self.leaf_closed)
+        txf, tri_leaf, flat = table(n_tris, i32, ts, self.tri_xform), table(n_tris, i32, ts, self.tri_leaf), table(n_tris, bool, ts, self.tri_flat)
+        rows = np.zeros((n_tris, 18))
+        run_items = []
+        for leaf0, n, xrow, mat, tri0, block, in_csg in self.runs:
+            leaf_kind[leaf0:leaf0 + n], leaf_xform[leaf0:leaf0 + n], leaf_material[leaf0:leaf0 + n] = K_TRIANGLE, xrow, mat
+            leaf_tri[leaf0:leaf0 + n] = np.arange(tri0, tri0 + n)
+            txf[tri0:tri0 + n], tri_leaf[tri0:tri0 + n] = xrow, np.arange(leaf0, leaf0 + n)
+            rows[tri0:tri0 + n] = block
+            if not in_csg:
+                run_items.append(np.stack([np.full(n, K_TRIANGLE, np.int64), np.arange(leaf0, leaf0 + n, dtype=np.int64)], axis=1))
         leaf_noshadow = (mat_shadow[leaf_material] == 0) if n_leaves else np.zeros(0, bool)
 
         # triangles -> world space, in bulk per transform
-        n_tris = len(self.tri_rows)
         tri_geom = np.zeros((max(n_tris, 1), 12))
         tri_norm = np.zeros((max(n_tris, 1), 12))
         tri_lo = np.zeros((n_tris, 3))
         tri_hi = np.zeros((n_tris, 3))
         if n_tris:
-            txf = np.array(self.tri_xform, i32)
-            flat = np.array(self.tri_flat, bool)
-            rows = np.zeros((n_tris, 18))
+            single = ts                                                                 # rows that came object by object
             for is_flat, k in ((True, 3), (False, 6)):
-                sel = np.nonzero(flat == is_flat)[0]
-                if sel.size:
+                pick = np.nonzero(flat[single] == is_flat)[0] if single.size else single
+                if pick.size:
                     try:
-                        block = np.array([self.tri_rows[i] for i in sel], f64)           # (n, k, 3 or 4)
+                        block = np.array([self.tri_rows[i] for i in pick], f64)          # (n, k, 3 or 4)
                     except ValueError:                                                  # mixed 3- and 4-component tuples
-                        block = np.array([[np.asarray(v, f64)[:3] for v in self.tri_rows[i]] for i in sel], f64)
-                    rows[sel, :3 * k] = block[:, :, :3].reshape(sel.size, 3 * k)
+                        block = np.array([[np.asarray(v, f64)[:3] for v in self.tri_rows[i]] for i in pick], f64)
+                    rows[single[pick], :3 * k] = block[:, :, :3].reshape(pick.size, 3 * k)
             for xi in np.unique(txf):
                 sel = np.nonzero(txf == xi)[0]
                 m = xf[xi]
@@ -332,62 +375,56 @@ class _Compiler(object):
         # world AABB per leaf as arrays (NaN = no finite box): analytic leaves from the walk, triangles in bulk
         leaf_lo = np.full((n_leaves, 3), np.nan)
         leaf_hi = np.full((n_leaves, 3), np.nan)
-        for leaf, (lo, hi) in enumerate(zip(self.leaf_lo, self.leaf_hi)):
-            if lo is not None:
-                leaf_lo[leaf], leaf_hi[leaf] = lo, hi
+        for leaf, lo, hi in self.leaf_lo:
+            leaf_lo[leaf], leaf_hi[leaf] = lo, hi
         if n_tris:
-            tl = np.array(self.tri_leaf, i32)
-            leaf_lo[tl], leaf_hi[tl] = tri_lo, tri_hi
+            leaf_lo[tri_leaf], leaf_hi[tri_leaf] = tri_lo, tri_hi
 
-        # items for the BVH / the unbounded list
-        leaf_tri = np.array(self.leaf_tri, i32).reshape(-1)
+        # items for the BVH / the unbounded list (in leaf order, as one walk of the tree would have listed them)
 
-        def codes(pairs):
-            if not pairs:
-                return np.zeros(0, i32)
-            kinds = np.array([k for k, _ in pairs], np.uint32)
-            leaves = np.array([l for _, l in pairs], np.int64)
+        def codes(pairs, more=()):
+            both = np.concatenate([np.array(pairs, np.int64).reshape(-1, 2)] + list(more))
+            if len(more):
+                both = both[np.argsort(both[:, 1], kind="stable")]
+            if not len(both):
+                return np.zeros(0, i32), np.zeros(0, np.int64)
+            kinds, leaves = both[:, 0].astype(np.uint32), both[:, 1]
             idx = np.where(kinds == K_TRIANGLE, leaf_tri[leaves], leaves).astype(np.uint32)
-            return ((kinds << 28) | (leaf_noshadow[leaves].astype(np.uint32) << 27) | (idx & 0x07FFFFFF)).view(i32)
+            return ((kinds << 28) | (leaf_noshadow[leaves].astype(np.uint32) << 27) | (idx & 0x07FFFFFF)).view(i32), leaves
 
-        item_leaves = np.array([l for _, l in self.items], np.int64)
-        item_prim = list(codes(self.items))
-        item_lo = list(leaf_lo[item_leaves]) if len(item_leaves) else []
-        item_hi = list(leaf_hi[item_leaves]) if len(item_leaves) else []
-        unb = list(codes(self.unbounded))
+        item_prim, item_leaves = codes(self.items, run_items)
+        item_lo, item_hi = leaf_lo[item_leaves], leaf_hi[item_leaves]
+        unb = list(codes(self.unbounded)[0])
+        root_prim, root_lo, root_hi = [], [], []
         for root, (_, _, l0, l2) in enumerate(self.csg_roots):
             los, his = leaf_lo[l0:l2], leaf_hi[l0:l2]
             if not (np.all(np.isfinite(los)) and np.all(np.isfinite(his))):
                 unb.append(prim_code(K_CSG_ROOT, False, root))
             else:
-                item_prim.append(prim_code(K_CSG_ROOT, False, root))
-                item_lo.append(np.min(los, axis=0))
-                item_hi.append(np.max(his, axis=0))
+                root_prim.append(prim_code(K_CSG_ROOT, False, root))
+                root_lo.append(np.min(los, axis=0))
+                root_hi.append(np.max(his, axis=0))
+        if root_prim:
+            item_prim = np.concatenate([item_prim, np.array(root_prim, i32)])
+            item_lo = np.concatenate([item_lo, np.array(root_lo, f64).reshape(-1, 3)])
+            item_hi = np.concatenate([item_hi, np.array(root_hi, f64).reshape(-1, 3)])
         # an item with non-finite bounds (degenerate transform) is tested for every ray instead
-        if item_prim:
-            lo_a, hi_a = np.array(item_lo, f64).reshape(-1, 3), np.array(item_hi, f64).reshape(-1, 3)
-            ok = np.all(np.isfinite(lo_a), axis=1) & np.all(np.isfinite(hi_a), axis=1)
+        if len(item_prim):
+            ok = np.all(np.isfinite(item_lo), axis=1) & np.all(np.isfinite(item_hi), axis=1)
             if not ok.all():
-                unb.extend(p for p, k in zip(item_prim, ok) if not k)
-                item_prim = [p for p, k in zip(item_prim, ok) if k]
-                item_lo, item_hi = lo_a[ok], hi_a[ok]
-            else:
-                item_lo, item_hi = lo_a, hi_a
+                unb.extend(item_prim[~ok])
+                item_prim, item_lo, item_hi = item_prim[ok], item_lo[ok], item_hi[ok]
 
         def arr(x, dt, shape):
             a = np.ascontiguousarray(np.array(x, dt).reshape(shape))
             return a if a.size else np.zeros([max(1, s) if s != -1 else 1 for s in shape], dt)
 
-        A["leaf_kind"] = arr(self.leaf_kind, i32, (-1,))
-        A["leaf_xform"] = arr(self.leaf_xform, i32, (-1,))
-        A["leaf_material"] = arr(self.leaf_material, i32, (-1,))
-        A["leaf_tri"] = arr(self.leaf_tri, i32, (-1,))
-        A["leaf_minmax"] = arr(self.leaf_minmax, f64, (-1, 2))
-        A["leaf_closed"] = arr(self.leaf_closed, i32, (-1,))
+        A["leaf_kind"], A["leaf_xform"], A["leaf_material"] = arr(leaf_kind, i32, (-1,)), arr(leaf_xform, i32, (-1,)), arr(leaf_material, i32, (-1,))
+        A["leaf_tri"], A["leaf_minmax"], A["leaf_closed"] = arr(leaf_tri, i32, (-1,)), arr(leaf_minmax, f64, (-1, 2)), arr(leaf_closed, i32, (-1,))
         A["xform"] = arr(xf[:, :3, :], f64, (-1, 12))
         A["tri_geom"] = np.ascontiguousarray(tri_geom)
         A["tri_norm"] = np.ascontiguousarray(tri_norm)
-        A["tri_leaf"] = arr(self.tri_leaf, i32, (-1,))
+        A["tri_leaf"] = arr(tri_leaf, i32, (-1,))
         A["item_prim"] = arr(item_prim, i32, (-1,))
         A["item_lo"] = arr(item_lo, f64, (-1, 3))
         A["item_hi"] = arr(item_hi, f64, (-1, 3))
@@ -433,7 +470,7 @@ class _Compiler(object):
         A["light_geom"] = arr(geom, f64, (-1, 9))
         A["light_steps"] = arr(steps, i32, (-1, 3))
         A["light_intensity"] = arr(inten, f64, (-1, 3))
-        C.update(n_leaves=n_leaves, n_xforms=len(self.xforms), n_tris=n_tris, n_items=len(item_prim),
+        C.update(n_leaves=n_leaves, n_xforms=len(self.xforms), n_tris=n_tris, n_items=int(len(item_prim)),
                  n_unbounded=len(unb), n_csg_roots=len(self.csg_roots), n_csg_nodes=len(self.csg_nodes),
                  n_materials=len(self.materials), n_pat_nodes=len(P), n_programs=len(self.programs),
                  n_instr=len(self.instr), n_textures=len(self.textures), tex_bytes=off, n_lights=len(lights))

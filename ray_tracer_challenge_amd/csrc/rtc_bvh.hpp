@@ -7,9 +7,12 @@
 // compiler supplies; output is the linear two-children-per-node layout rtc_device.hpp walks.
 #pragma once
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <limits>
+#include <thread>
 #include <vector>
 
 #ifndef RTC_SAH_BINS
@@ -51,19 +54,48 @@ public:
         cen_.resize(3 * (size_t)n);
         for (int i = 0; i < n; i++)
             for (int k = 0; k < 3; k++) cen_[3 * (size_t)i + k] = 0.5 * (b_[i].lo[k] + b_[i].hi[k]);
-        out_ = &out;
         if (n == 0) return out;
         if (n <= max_leaf_) {   // a single leaf: node 0 with one child
-            int node = new_node();
+            int node = new_node(out);
             Aabb bb = bounds(0, n);
-            set_child(node, 0, leaf_code(0, n), bb);
+            set_child(out, node, 0, leaf_code(0, n), bb);
             Aabb e; e.reset();
-            set_child(node, 1, EMPTY, e);
+            set_child(out, node, 1, EMPTY, e);
             out.depth = 1;
             out.max_leaf = n;
         } else {
+            // Large inputs: the top of the tree is built here; every range of at most `grain` items is set aside as a task;
+            // the tasks are built by a few threads into trees of their own (they partition disjoint ranges of idx_) and
+            // spliced in behind the top in the order they were set aside.  The tree is the one a single thread builds --
+            // only the numbering of its nodes differs, and that depends on the input alone, not on the number of threads.
+            const int threads = std::max(1, std::min<int>(getenv("RTC_BUILD_THREADS") ? atoi(getenv("RTC_BUILD_THREADS")) : 16, (int)std::thread::hardware_concurrency()));
+            std::vector<Task> tasks;
+            Target top = {&out, n >= 32768 ? &tasks : nullptr, std::max(4096, n / 64)};
             Aabb bb;
-            split(0, n, 1, bb);
+            split(0, n, 1, bb, top);
+            if (!tasks.empty()) {
+                std::vector<Bvh> subs(tasks.size());
+                std::atomic<size_t> next(0);
+                auto work = [&]() {
+                    for (size_t t = next.fetch_add(1); t < tasks.size(); t = next.fetch_add(1)) {
+                        Target mine = {&subs[t], nullptr, 0};
+                        Aabb unused;
+                        split(tasks[t].lo, tasks[t].hi, tasks[t].depth, unused, mine);
+                    }
+                };
+                std::vector<std::thread> pool;
+                for (int t = 1; t < threads && t < (int)tasks.size(); t++) pool.emplace_back(work);
+                work();
+                for (std::thread& th : pool) th.join();
+                for (size_t t = 0; t < tasks.size(); t++) {
+                    const int32_t offset = out.n_nodes();
+                    out.box.insert(out.box.end(), subs[t].box.begin(), subs[t].box.end());
+                    for (int32_t c : subs[t].child) out.child.push_back(c >= 0 ? c + offset : c);
+                    out.child[2 * (size_t)tasks[t].node + tasks[t].side] = offset;
+                    out.depth = std::max(out.depth, subs[t].depth);
+                    out.max_leaf = std::max(out.max_leaf, subs[t].max_leaf);
+                }
+            }
         }
         out.order = idx_;
         return out;
@@ -75,18 +107,19 @@ private:
     bool median_;
     std::vector<int32_t> idx_;
     std::vector<double> cen_;
-    Bvh* out_ = nullptr;
+    struct Task { int lo, hi, depth, node, side; };
+    struct Target { Bvh* out; std::vector<Task>* tasks; int grain; };      // where split() puts its nodes, and which ranges it sets aside instead
 
     static int32_t leaf_code(int first, int count) { return ~((first << 4) | (count - 1)); }
-    int new_node() {
-        out_->box.resize(out_->box.size() + 12);
-        out_->child.resize(out_->child.size() + 2);
-        return out_->n_nodes() - 1;
+    static int new_node(Bvh& out) {
+        out.box.resize(out.box.size() + 12);
+        out.child.resize(out.child.size() + 2);
+        return out.n_nodes() - 1;
     }
-    void set_child(int node, int k, int32_t ref, const Aabb& bb) {
-        double* p = out_->box.data() + 12 * (size_t)node + 6 * k;
+    static void set_child(Bvh& out, int node, int k, int32_t ref, const Aabb& bb) {
+        double* p = out.box.data() + 12 * (size_t)node + 6 * k;
         for (int a = 0; a < 3; a++) { p[a] = bb.lo[a]; p[3 + a] = bb.hi[a]; }
-        out_->child[2 * (size_t)node + k] = ref;
+        out.child[2 * (size_t)node + k] = ref;
     }
     Aabb bounds(int lo, int hi) const {
         Aabb bb; bb.reset();
@@ -94,10 +127,11 @@ private:
         return bb;
     }
 
-    // builds the inner node for items [lo, hi) (hi - lo > max_leaf) and returns its index
-    int split(int lo, int hi, int depth, Aabb& bb_out) {
-        int node = new_node();
-        out_->depth = std::max(out_->depth, depth);
+    // builds the inner node for items [lo, hi) (hi - lo > max_leaf) into tg.out and returns its index there
+    int split(int lo, int hi, int depth, Aabb& bb_out, Target& tg) {
+        Bvh& out = *tg.out;
+        int node = new_node(out);
+        out.depth = std::max(out.depth, depth);
         int n = hi - lo;
         Aabb cb; cb.reset();
         for (int i = lo; i < hi; i++)
@@ -163,17 +197,27 @@ private:
             if (b - a <= max_leaf_) {
                 bb = bounds(a, b);
                 ref = leaf_code(a, b - a);
-                out_->max_leaf = std::max(out_->max_leaf, b - a);
-                out_->depth = std::max(out_->depth, depth);
+                out.max_leaf = std::max(out.max_leaf, b - a);
+                out.depth = std::max(out.depth, depth);
+            } else if (tg.tasks && b - a <= tg.grain) {
+                bb = bounds(a, b);                     // = what the subtree's own boxes add up to (min / max are exact)
+                ref = 0;                               // filled in when the task's tree is spliced in
+                tg.tasks->push_back({a, b, depth + 1, node, k});
             } else {
-                ref = split(a, b, depth + 1, bb);
+                ref = split(a, b, depth + 1, bb, tg);
             }
-            set_child(node, k, ref, bb);
+            set_child(*tg.out, node, k, ref, bb);
             bb_out.grow(bb);
         }
         return node;
     }
 };
+
+inline Bvh build_bvh(const std::vector<Aabb>& boxes, int max_leaf, int max_depth) {
+    Bvh b = BvhBuilder(boxes, max_leaf, false).build();
+    if (b.depth > max_depth) b = BvhBuilder(boxes, max_leaf, true).build();
+    return b;
+}
 
 // ---- four children per node ------------------------------------------------------------------------------------
 // The binary tree collapsed two levels at a time: a wide node starts as a binary node's two children, and the child box
@@ -298,11 +342,5 @@ private:
 };
 
 inline Bvh4 collapse_bvh4(const Bvh& b, int budget) { return Bvh4Collapser(b, budget).run(); }
-
-inline Bvh build_bvh(const std::vector<Aabb>& boxes, int max_leaf, int max_depth) {
-    Bvh b = BvhBuilder(boxes, max_leaf, false).build();
-    if (b.depth > max_depth) b = BvhBuilder(boxes, max_leaf, true).build();
-    return b;
-}
 
 }  // namespace rtc

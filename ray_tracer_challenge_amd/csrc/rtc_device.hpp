@@ -52,14 +52,6 @@
 #ifndef RTC_BLOCK_CSG
 #define RTC_BLOCK_CSG RTC_BLOCK_PLAIN
 #endif
-// how many levels of a pixel's ray tree its 16 (2x2 parts) / 4 (4x4 parts) lanes trace together before the subtrees are
-// dealt out among them (trace_tree_dealt); 0 = all lanes walk the whole tree (round 2's form)
-#ifndef RTC_DEAL16_LEVELS
-#define RTC_DEAL16_LEVELS 2
-#endif
-#ifndef RTC_DEAL4_LEVELS
-#define RTC_DEAL4_LEVELS 1
-#endif
 #ifndef RTC_BVH4_SORT_ANYHIT
 #define RTC_BVH4_SORT_ANYHIT 0   // development: 1 = shadow rays and container passes sort the children of a four-wide node like nearest-hit queries do
 #endif
@@ -1589,112 +1581,10 @@ __device__ __forceinline__ V3<R> trace_tree(const DScene<R>& S, Ray<R> ray, V3<R
     return color;
 }
 
-// ------------------------------------------------------------------------------------------
-// The ray tree of a pixel that 16 lanes trace (the 2x2 parts of the dearest units, DFrame::replicas): a launch cannot end
-// before its longest wave, and the longest wave is ONE pixel's tree of glass / mirror bounces walked ray after ray -- up to
-// 63 rays at depth 5, each a nearest-hit walk and a round of shadow walks (dragons 1080p: 403 us of a 403 us launch,
-// profiles/r03_experiments/timeline_four_wide_bvh.txt).  So the tree is dealt out: the camera ray and its two children
-// (rays 1, 2, 3 in the heap numbering above) are traced by all 16 lanes as before (they share the shadow rays); the four
-// grandchildren 4 .. 7 are the roots of four subtrees, and subtree 4 + g is traced by the four lanes 4 g .. 4 g + 3 (which
-// share ITS shadow rays), all four subtrees at once.  The reference adds the rays' contributions up in the order of its
-// recursion -- here: the order trace_tree's stack visits them, parent, reflection subtree, refraction subtree -- and a
-// floating-point sum depends on its order, so nothing is summed in parallel: every lane group records its subtree's terms
-// (weight x surface colour, in its own visiting order), and then every lane adds ALL terms of the pixel in the one order,
-// fetching the other groups' terms across lanes.  Same values, same order, same colour to the last bit as one lane's loop.
-// ------------------------------------------------------------------------------------------
-#define RTC_SPLIT_TERMS 31     /* rays of one dealt-out subtree at most: 2^max_depth - 1 with max_depth <= 6, less the levels above it */
-#define RTC_SPLIT_MAX_GROUPS 8
-// Children of a ray of the shared top of the tree: onto the stack like PushPending's, except the ones on the level that is
-// dealt out (heap numbers >= groups), which are set aside as the roots of the subtrees.
-template <class R, class CNT> struct DealChildren {
-    Bounce<R>* pending; int& np; Bounce<R>* root; bool* has_root; const bool& top; const int& groups;
-    const V3<R>& weight; const int& remaining; const uint32_t& path; CNT& cnt;
-    __device__ __forceinline__ void put(const Bounce<R>& b) {
-        if (top && (int)b.path >= groups) { root[b.path - groups] = b; has_root[b.path - groups] = true; }
-        else if (np < RTC_MAX_BOUNCE_STACK) pending[np++] = b;
-    }
-    __device__ __forceinline__ bool operator()(bool refl, V3<R> refl_o, V3<R> refl_d, R w_refl, bool refr, V3<R> refr_o, V3<R> refr_d, R w_refr) {
-        if (refr) { Bounce<R> b = {refr_o, refr_d, weight * w_refr, remaining - 1, 2 * path + 1}; put(b); cnt.c[3]++; }
-        if (refl) { Bounce<R> b = {refl_o, refl_d, weight * w_refl, remaining - 1, 2 * path}; put(b); cnt.c[2]++; }
-        return true;
-    }
-};
-__device__ __forceinline__ float lane_get(float v, int src) { return __shfl(v, src, 64); }
-__device__ __forceinline__ double lane_get(double v, int src) { return __shfl(v, src, 64); }
-
-// `levels` = how many levels of the tree all lanes of the pixel trace together (1: the camera ray; 2: and its children; ...);
-// the 2^levels rays of the next level are the roots of the subtrees, one per group of nrep / 2^levels lanes.
-template <class R, class CNT>
-__device__ __forceinline__ V3<R> trace_tree_dealt(const DScene<R>& S, Ray<R> ray, int max_depth, int levels, R shade_eps, R shade_eps_rel, int* stack,
-                                                  CNT& cnt, uint64_t seed, uint32_t pixel, int& first_leaf) {
-    const int lane = threadIdx.x & 63, nrep_all = cnt.nrep, rep_all = cnt.rep, base = lane & ~(nrep_all - 1);
-    const int groups = 1 << levels, per_group = nrep_all / groups, g = rep_all / per_group;
-    V3<R> term_top[RTC_SPLIT_MAX_GROUPS - 1], terms[RTC_SPLIT_TERMS];
-    bool has_top[RTC_SPLIT_MAX_GROUPS - 1], has_root[RTC_SPLIT_MAX_GROUPS];
-    Bounce<R> root[RTC_SPLIT_MAX_GROUPS], pending[RTC_MAX_BOUNCE_STACK];
-    for (int k = 0; k < RTC_SPLIT_MAX_GROUPS - 1; k++) has_top[k] = false;
-    for (int k = 0; k < RTC_SPLIT_MAX_GROUPS; k++) has_root[k] = false;
-    int np = 0, n_terms = 0, remaining = max_depth;
-    uint32_t path = 1u;
-    V3<R> weight = mk<R>(1, 1, 1);
-    bool top = true, ran_subtree = false;
-    unsigned int keep2 = 0, keep3 = 0;
-    first_leaf = -1;
-    while (true) {
-        int leaf;
-        DealChildren<R, CNT> deal = {pending, np, root, has_root, top, groups, weight, remaining, path, cnt};
-        V3<R> surface = shade_ray(S, ray, remaining, path, shade_eps, shade_eps_rel, stack, cnt, seed, pixel, leaf, deal);
-        if (path == 1u) first_leaf = leaf;
-        if (leaf >= 0) {
-            if (top) { term_top[path - 1] = weight * surface; has_top[path - 1] = true; }
-            else if (n_terms < RTC_SPLIT_TERMS) terms[n_terms++] = weight * surface;
-        }
-        if (np > 0) {
-            np--;
-            ray.o = pending[np].o; ray.d = pending[np].d; weight = pending[np].w; remaining = pending[np].remaining; path = pending[np].path;
-            continue;
-        }
-        if (!top) break;
-        // the shared top of the tree is done: on to this group's subtree, if the tree has one there
-        top = false;
-        if (rep_all != 0) cnt.c[2] = cnt.c[3] = 0;          // every lane of the pixel counted the top rays' children: once is enough
-        if (!has_root[g]) break;
-        ran_subtree = true;
-        keep2 = cnt.c[2]; keep3 = cnt.c[3];
-        cnt.nrep = per_group; cnt.rep = rep_all % per_group;
-        ray.o = root[g].o; ray.d = root[g].d; weight = root[g].w; remaining = root[g].remaining; path = root[g].path;
-    }
-    if (ran_subtree && cnt.rep != 0) { cnt.c[2] = keep2; cnt.c[3] = keep3; }       // the lanes of a group counted the same rays
-    cnt.nrep = nrep_all; cnt.rep = rep_all;
-    // every term of the pixel in the order ONE lane's stack visits the rays: a ray, its reflection subtree, its refraction subtree
-    V3<R> color = mk<R>(0, 0, 0);
-    uint32_t todo[8];
-    int nt = 0;
-    todo[nt++] = 1u;
-    while (nt > 0) {
-        const uint32_t p = todo[--nt];
-        if ((int)p < groups) {
-            if (has_top[p - 1]) { color = color + term_top[p - 1]; todo[nt++] = 2 * p + 1; todo[nt++] = 2 * p; }
-        } else {
-            const int src = base + ((int)p - groups) * per_group;
-            const int count = __shfl(n_terms, src, 64);
-            for (int k = 0; k < count; k++) {
-                const V3<R> t = terms[k < RTC_SPLIT_TERMS ? k : 0];
-                color = color + mk<R>(lane_get(t.x, src), lane_get(t.y, src), lane_get(t.z, src));
-            }
-        }
-    }
-    return color;
-}
-
 // color_at for one primary ray (the single-kernel form)
 template <class R, class CNT>
 __device__ __forceinline__ V3<R> trace_pixel(const DScene<R>& S, Ray<R> primary, int max_depth, R shade_eps, R shade_eps_rel, int* stack,
                                              CNT& cnt, uint64_t seed, uint32_t pixel, int& hit_leaf_out) {
-    if (CNT::kReplicas && cnt.nrep > 1) {
-        const int levels = cnt.nrep == 16 ? RTC_DEAL16_LEVELS : RTC_DEAL4_LEVELS;
-        if (levels > 0) return trace_tree_dealt(S, primary, max_depth, levels, shade_eps, shade_eps_rel, stack, cnt, seed, pixel, hit_leaf_out);
-    }
     V3<R> c = trace_tree(S, primary, mk<R>(1, 1, 1), max_depth, 1u, shade_eps, shade_eps_rel, stack, cnt, seed, pixel, hit_leaf_out);
     if (CNT::kReplicas && cnt.rep != 0) cnt.c[2] = cnt.c[3] = 0;      // replicas trace the same reflection and refraction rays: counted once
     return c;

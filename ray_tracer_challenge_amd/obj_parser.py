@@ -21,6 +21,7 @@ class OBJParser(object):
         self.vertices = [None]
         self.normals = [None]
         self.named_groups = {self.DEFAULT: Group(self.default_material, matrix4x4identity(), [])}
+        self.face_indices = {self.DEFAULT: []}          # per group: (v1, v2, v3, n1, n2, n3) of every triangle, in order
         self.current_group_name = self.DEFAULT
         self.default_group = self.named_groups[self.DEFAULT]
         for line in open_file:
@@ -43,11 +44,17 @@ class OBJParser(object):
         self.normals.append(vector(*[float(c) for c in tok[1:4]]))
 
     def _face(self, tok):
-        self.named_groups[self.current_group_name].add_child(self._fan_triangulation(tok))
+        group = self.named_groups[self.current_group_name]
+        before = len(group.children)
+        tris, idx = self._fan_triangulation(tok)
+        group.add_child(tris)
+        if len(group.children) == before + len(tris):
+            self.face_indices[self.current_group_name].extend(idx)
 
     def _group(self, tok):
         name = tok[1]
         self.named_groups.setdefault(name, Group(self.default_material, matrix4x4identity(), []))
+        self.face_indices.setdefault(name, [])
         self.current_group_name = name
 
     _RECORDS = {"v": _vertex, "vn": _normal, "f": _face, "g": _group}
@@ -62,7 +69,7 @@ class OBJParser(object):
     def _fan_triangulation(self, tok):
         corners = [self._corner(t) for t in tok[1:]]
         v1, n1 = corners[0]
-        out = []
+        out, idx = [], []
         for (v2, n2), (v3, n3) in zip(corners[1:-1], corners[2:]):
             if n1 is None or n2 is None or n3 is None:
                 raise ValueError("face without vertex normals: the reference always builds "
@@ -70,7 +77,8 @@ class OBJParser(object):
             out.append(SmoothTriangle(self.default_material, matrix4x4identity(),
                                       self.vertices[v1], self.vertices[v2], self.vertices[v3],
                                       self.normals[n1], self.normals[n2], self.normals[n3]))
-        return out
+            idx.append((v1, v2, v3, n1, n2, n3))
+        return out, idx
 
     @classmethod
     def from_yaml(cls, obj, defines):
@@ -84,7 +92,27 @@ class OBJParser(object):
 def obj_to_group(parser):
     outer = Group(Material(), matrix4x4identity(), [])
     outer.add_child([g for g in parser.named_groups.values() if len(g.children) > 0])
+    _record_triangle_runs(parser)
     return outer
+
+
+def _record_triangle_runs(parser):
+    """Every named group's triangles as one block of vertex data beside the objects (shapes.TriangleRun): the scene
+    compiler flattens a mesh from the block instead of from its tens of thousands of triangle objects."""
+    import numpy as np
+    from .shapes import TriangleRun
+    if len(parser.vertices) < 2 or len(parser.normals) < 2:
+        return
+    V = np.array([np.asarray(p.arr, dtype=np.float64)[:3] for p in parser.vertices[1:]])
+    N = np.array([np.asarray(n.arr, dtype=np.float64)[:3] for n in parser.normals[1:]])
+    for name, g in parser.named_groups.items():
+        idx = np.array(parser.face_indices.get(name, []), dtype=np.int64).reshape(-1, 6)
+        if len(idx) == 0 or len(idx) != len(g.children) or g.triangle_runs:
+            continue
+        if (idx < 0).any():                               # negative (relative) indices resolve like Python's, as in the lists
+            idx = np.where(idx < 0, idx + np.array([len(parser.vertices)] * 3 + [len(parser.normals)] * 3), idx)
+        rows = np.concatenate([V[idx[:, 0] - 1], V[idx[:, 1] - 1], V[idx[:, 2] - 1], N[idx[:, 3] - 1], N[idx[:, 4] - 1], N[idx[:, 5] - 1]], axis=1)
+        g.triangle_runs.append(TriangleRun(0, g.children, rows))
 
 
 def obj_file_to_group(file_path, material=None):

@@ -230,10 +230,14 @@ class _Loader(object):
                 return [S.Triangle(mat, xf, *pts)]
             return [S.SmoothTriangle(mat, xf, *pts, *[Tuple4(np.append(r[k:k + 3], 0.0)) for k in (9, 12, 15)])]
         if name == "Group":
-            kids = []
+            g = S.Group(mat, xf, [])
             for c in d["children"]:
-                kids.extend(self.node(c))
-            return [S.Group(mat, xf, kids)]
+                if c["kind"] == "SmoothTriangleRun":       # the compiler flattens such a run from the array itself (shapes.TriangleRun)
+                    rows = self.arrays[c["array"]]
+                    g.add_triangle_run(self._tris(rows, self.material(c["material"])), rows[:, :18])
+                else:
+                    g.add_child(self.node(c))
+            return [g]
         if name == "CSG":
             return [S.CSG(mat, xf, _OPS[d["op"]], self.node(d["left"])[0], self.node(d["right"])[0])]
         raise ValueError("unknown shape kind in pack: " + name)

@@ -252,6 +252,32 @@ class SmoothTriangle(Triangle):
         self.n1, self.n2, self.n3 = n1, n2, n3
 
 
+class TriangleRun(object):
+    """`count` consecutive children of a Group, from index `start`, that a loader made from one block of vertex data:
+    rows[i] = p1, p2, p3, n1, n2, n3 (18 numbers) of child start + i -- SmoothTriangles with the identity transform and
+    one shared material.  The scene compiler flattens such a run from `rows` in one NumPy step instead of reading six
+    attributes of each of (for the dragons) 140 940 triangle objects; it first checks that the run still is what the
+    loader made -- the same objects at both ends and in the middle, with the same vertices -- and reads the objects
+    otherwise.  Code that moves the triangles of a loaded mesh clears `group.triangle_runs`."""
+
+    def __init__(self, start, triangles, rows):
+        self.start, self.count, self.rows = int(start), len(triangles), rows
+        self.probes = [(k, triangles[k]) for k in sorted({0, len(triangles) // 2, len(triangles) - 1})] if triangles else []
+        self.material = triangles[0].material if triangles else None
+
+    def still_valid(self, children):
+        if self.count == 0 or self.start + self.count > len(children):
+            return False
+        for k, tri in self.probes:
+            c = children[self.start + k]
+            if c is not tri or c.material is not self.material or type(c).__name__ != "SmoothTriangle":
+                return False
+            got = np.concatenate([np.asarray(getattr(v, "arr", v), dtype=np.float64)[:3] for v in (c.p1, c.p2, c.p3, c.n1, c.n2, c.n3)])
+            if not np.array_equal(got, self.rows[k]) or not np.array_equal(np.asarray(c.transform.arr), np.eye(4)):
+                return False
+        return True
+
+
 class Group(Shape):
     """Children are kept in insertion order (the reference uses a set, so its order is
     arbitrary); order only matters for hits at exactly equal `t`."""
@@ -260,7 +286,15 @@ class Group(Shape):
         Shape.__init__(self, material, transform)
         self.children = []
         self._child_ids = set()
+        self.triangle_runs = []          # TriangleRun records of loader-made meshes among the children (may be empty)
         self.add_child(list(children))
+
+    def add_triangle_run(self, triangles, rows):
+        """Appends loader-made triangles (see TriangleRun) as children and remembers the block of vertex data behind them."""
+        start = len(self.children)
+        self.add_child(triangles)
+        if len(self.children) == start + len(triangles):
+            self.triangle_runs.append(TriangleRun(start, triangles, np.ascontiguousarray(rows, dtype=np.float64)))
 
     @classmethod
     def from_yaml(cls, tree, defines):
@@ -304,6 +338,7 @@ class Group(Shape):
         # the sub-group is built with a copy of THIS group's transform (shapes.py:492):
         # harmless for identity, a double application otherwise.
         ids = set(id(c) for c in children)
+        self.triangle_runs = []               # positions change
         self.children = [c for c in self.children if id(c) not in ids]
         self._child_ids -= ids
         self.add_child(Group(self.material, self.transform, children))

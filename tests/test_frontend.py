@@ -416,3 +416,60 @@ def test_macro_language_matches_reference_loader(tmp_path):
     assert tree_a == tree_b
     skewed = [e for e in tree_a if e.get("define") == "skewed"][0]["value"]
     assert skewed[:2] == [["rotate-y", 0.4], ["translate", 0, 1, 0]]          # the parent's items, reversed, in front
+
+
+def _drop_runs(world):
+    todo = list(world.contains)
+    while todo:
+        o = todo.pop()
+        if hasattr(o, "children"):
+            o.triangle_runs = []
+            todo.extend(o.children)
+
+
+def _same_compiled(a, b):
+    assert a.counts == b.counts
+    for k in a.arrays:
+        assert a.arrays[k].dtype == b.arrays[k].dtype and np.array_equal(a.arrays[k], b.arrays[k]), k
+    assert all(x is y for x, y in zip(a.leaf_objects, b.leaf_objects))
+
+
+def test_triangle_runs_flatten_like_the_objects():
+    """Loader-made meshes carry their vertex data as one block beside the triangle objects (shapes.TriangleRun) and
+    compile_scene flattens them from the block: the arrays must be exactly what reading the objects one by one gives --
+    for the scene packs, for OBJ text through the parser (several named groups, a transform above them, a primitive in
+    between), and after Group.divide (which drops the runs) -- and a run whose triangles were moved is not trusted."""
+    for name in ("teapot", "dragons"):
+        cam, world, _ = load_pack(name)
+        todo, in_runs = list(world.contains), 0
+        while todo:
+            o = todo.pop()
+            if hasattr(o, "children"):
+                in_runs += sum(r.count for r in o.triangle_runs)
+                todo.extend(o.children)
+        assert in_runs == {"teapot": 6320, "dragons": 140940}[name]
+        fast = compile_scene(world)
+        _drop_runs(world)
+        _same_compiled(fast, compile_scene(world))
+    rng = np.random.default_rng(4)
+    lines = ["v %.6f %.6f %.6f" % tuple(v) for v in rng.uniform(-1, 1, (40, 3))] + ["vn %.6f %.6f %.6f" % tuple(v) for v in rng.uniform(-1, 1, (40, 3))]
+    for gname in ("A", "B"):
+        lines.append("g " + gname)
+        for _ in range(30):
+            k = rng.choice(np.arange(1, 41), size=int(rng.integers(3, 6)), replace=False)
+            lines.append("f " + " ".join("%d//%d" % (i, i) for i in k))
+    mesh = obj_to_group(OBJParser(io.StringIO("\n".join(lines)), default_material=S.Material(color=color(0.2, 0.5, 0.7))))
+    mesh.transform = translation(0.5, -1, 2) * rotation_x(0.4) * scaling(1.5, 0.7, 1.1)
+    assert all(len(g.triangle_runs) == 1 and g.triangle_runs[0].count == len(g.children) for g in mesh.children)
+    world = World([], [S.Group(S.Material(), translation(0, 1, 0), [S.sphere(), mesh, S.Cube(S.Material(), scaling(2, 2, 2))])])
+    fast = compile_scene(world)
+    assert fast.counts["n_tris"] == sum(len(g.children) for g in mesh.children) > 100
+    tri = mesh.children[1].children[len(mesh.children[1].children) // 2]
+    tri.p2 = point(9, 9, 9)                              # a probe triangle moved: that group's run is not trusted any more
+    moved = compile_scene(world)
+    assert not np.array_equal(moved.arrays["tri_geom"], fast.arrays["tri_geom"])
+    _drop_runs(world)
+    _same_compiled(moved, compile_scene(world))
+    mesh.divide(4)                                        # sub-groups are new groups: no runs, same leaves by another route
+    assert all(not g.triangle_runs for g in mesh.children)
+    assert compile_scene(world).counts["n_tris"] == fast.counts["n_tris"]
