@@ -44,15 +44,18 @@ FLOPS_SHADE, FLOPS_LIGHT, FLOPS_REFRACT = 85, 45, 40
 PEAK_TFLOPS = {"fp64": 78.6, "fp32": 157.3}      # MI355X vector peaks (MI355X_MICROARCH.md; fp64 = half the fp32 rate)
 
 
-def algorithmic_flops(work):
+def algorithmic_flops(work, wide=0):
+    """`work` = rtc_stats::work; `wide` of its node visits were to four-wide triangle-BVH nodes (4 slab tests), the others to
+    binary object-BVH nodes (2)."""
     node, tri, leaf, csg, shade, light, container, pattern = work
-    return (2 * FLOPS_AABB * node + FLOPS_TRI * tri + (FLOPS_XFORM + FLOPS_ANALYTIC) * leaf + FLOPS_SHADE * shade +
+    return (FLOPS_AABB * (2 * (node - wide) + 4 * wide) + FLOPS_TRI * tri + (FLOPS_XFORM + FLOPS_ANALYTIC) * leaf + FLOPS_SHADE * shade +
             FLOPS_LIGHT * light + FLOPS_REFRACT * container)
 
 
-def algorithmic_bytes(work, real_bytes):
-    node, tri, leaf = work[0], work[1], work[2]
-    # a node visit reads one 64-byte node (both child boxes as 12 fp32 + 2 child refs, in either precision);
+def algorithmic_bytes(work, real_bytes, wide=0):
+    node, tri, leaf = work[0] + wide, work[1], work[2]          # a four-wide record is two 64-byte halves
+    # a node visit reads one node record -- priced at 64 bytes, the binary object-BVH record (the four-wide triangle-BVH record is
+    # 112 of 128 bytes: the figure stays SURVEY.md 8d's so that rounds compare);
     # a triangle test p1,e1,e2,eps (10 reals); an analytic leaf test its 3x4 (12 reals)
     return node * 64 + tri * 10 * real_bytes + leaf * 12 * real_bytes
 
@@ -93,16 +96,23 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
 
+    t_load = time.perf_counter()
     cam, scene_world, _ = load_world(os.path.join(ROOT, "scenes", args.scene + ".npz"))
     cam = cam.resized(args.width, args.height)
+    t_compile = time.perf_counter()
     cs = compile_scene(scene_world)
+    t_create = time.perf_counter()
     scene = _ffi.Scene(cs, device=local_rank)
+    torch.cuda.synchronize()
+    t_ready = time.perf_counter()
     info = scene.info()
+    one_frame = {"load_scene_pack_ms": round((t_compile - t_load) * 1e3, 1), "compile_scene_ms": round((t_create - t_compile) * 1e3, 1),
+                 "rtc_scene_create_ms": round((t_ready - t_create) * 1e3, 1)}
 
     from ray_tracer_challenge_amd.dist import TILE as T, FramePipeline, render_pipelined
     pipe = FramePipeline(cam.hsize, cam.vsize, world, rank, dev, T)      # N > 1: frame k's gather overlaps frame k+1's tracing
     fg = pipe.sets[0]
-    rays_dev = torch.zeros(13, dtype=torch.int64, device=dev)
+    rays_dev = torch.zeros(14, dtype=torch.int64, device=dev)
     frame = fg.frame
 
     def step(precision, count_work=False, feedback=True):
@@ -156,7 +166,14 @@ def main():
         order = sorted(range(len(reps)), key=lambda i: reps[i])
         return order[len(order) // 2]
 
+    # the reference's own usage is ONE frame per scene (main.py:305-354): the first frame of a fresh handle, plain tile order
+    if world == 1:
+        t0 = time.perf_counter()
+        step("fp64")
+        torch.cuda.synchronize()
+        one_frame["first_frame_ms"] = round((time.perf_counter() - t0) * 1e3, 3)
     reps64, rays, launches64 = timed("fp64", args.steps, args.warmup, min_seconds=args.min_seconds)
+    launched64 = scene.last_launch()
     m64 = median_rep(reps64)
     dt = reps64[m64]
     total_rays = sum(rays[:4])            # rays actually traced; rays[4] = is_shadowed queries that needed none
@@ -166,15 +183,16 @@ def main():
     rays_dev.zero_()
     step("fp64", count_work=True)
     sync()
-    work = [int(v) for v in rays_dev[4:12].tolist()]
+    work, wide = [int(v) for v in rays_dev[4:12].tolist()], int(rays_dev[13].item())
     reps32, rays32, launches32 = timed("fp32", args.steps, args.warmup, min_seconds=args.min_seconds / 2)
+    launched32 = scene.last_launch()
     m32 = median_rep(reps32)
     dt32 = reps32[m32]
     kms32 = float(np.mean(launches32[m32]))
     rays_dev.zero_()
     step("fp32", count_work=True)
     sync()
-    work32 = [int(v) for v in rays_dev[4:12].tolist()]
+    work32, wide32 = [int(v) for v in rays_dev[4:12].tolist()], int(rays_dev[13].item())
     # for the record: the same frames launched in plain tile order (no cost feedback from the previous frame)
     plain = None
     frame_host = ids_host = None
@@ -188,9 +206,49 @@ def main():
                             stream=torch.cuda.current_stream().cuda_stream)
         torch.cuda.synchronize()
         frame_host, ids_host = frame.cpu().numpy(), ids_dev.cpu().numpy()
+        # the N = 1 frame through the multi-GPU path (tile list, compact buffer, tiles -> canvas): what a rank of N does, for one rank
+        for _ in range(8):
+            render_pipelined(scene, cam, pipe, "fp64", args.depth, rays_dev.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        sync_pipe = lambda: (pipe.drain(), torch.cuda.synchronize())
+        sync_pipe()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            render_pipelined(scene, cam, pipe, "fp64", args.depth, rays_dev.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        sync_pipe()
+        one_frame["pipelined_path_ms_per_frame_n1"] = round((time.perf_counter() - t0) / args.steps * 1e3, 4)
+        # and the whole drop-in call, as main.py makes it: render_multi(cam, world) -> ndarray (compile + upload + frame + copy back)
+        from ray_tracer_challenge_amd.renderer import render_multi
+        t0 = time.perf_counter()
+        arr = render_multi(cam, scene_world, 1)
+        one_frame["end_to_end_render_multi_ms"] = round((time.perf_counter() - t0) * 1e3, 1)
+        one_frame["end_to_end_equals_timed_frame"] = bool(np.array_equal(arr, frame_host))
+
+    # what every rank did: its share of the tiles, its kernel time per frame, and the gather on its own (N > 1)
+    per_rank = None
+    try:
+        mine_ms = float(np.mean(launches64[m64]))
+        gather_ms = 0.0
+        if world > 1:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            sync()
+            e0.record()
+            for _ in range(5):
+                fg.gather()
+            e1.record()
+            torch.cuda.synchronize()
+            gather_ms = e0.elapsed_time(e1) / 5
+        row = torch.tensor([mine_ms, gather_ms, float(len(fg.mine))], dtype=torch.float64, device=dev)
+        rows = [torch.zeros_like(row) for _ in range(world)]
+        if dist is not None:
+            dist.all_gather(rows, row)
+        else:
+            rows = [row]
+        per_rank = [{"rank": r, "kernel_ms": round(float(v[0]), 4), "gather_ms": round(float(v[1]), 4), "tiles": int(v[2])} for r, v in enumerate(rows)]
+    except Exception as e:          # noqa: BLE001 - reporting only
+        per_rank = {"error": repr(e)}
 
     if rank == 0:
-        flops = algorithmic_flops(work)
+        flops = algorithmic_flops(work, wide)
         achieved = flops / (kms64 * 1e-3) / 1e12
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
@@ -215,26 +273,32 @@ def main():
             "ms_per_frame": round(dt / args.steps * 1e3, 4),
             "launch_order": {"policy": "dearest 8x8 blocks first, from the wave costs the first two frames of a view record; the dearest blocks split into 4x4 / 2x2 parts whose pixels are traced by 4 / 16 lanes sharing the shadow rays (DESIGN.md 4.1)",
                              "ms_per_frame_plain_tile_order": None if plain is None else round(plain, 4)},
+            "n_ranks_seen": dist.get_world_size() if dist is not None else 1,
+            "per_rank": per_rank,
+            "one_frame_per_scene": one_frame,
             "fp32": {"value": round(sum(rays32[:4]) / dt32 / 1e6, 3), "unit": "Mrays/s", "ms_per_frame": round(dt32 / args.steps * 1e3, 4),
-                     "kernel_ms": round(kms32, 4), "repeats": len(reps32),
-                     "roofline": {"bound": "valu", "achieved": round(algorithmic_flops(work32) / (kms32 * 1e-3) / 1e12, 4),
+                     "kernel_ms": round(kms32, 4), "repeats": len(reps32), "kernel": launched32["kernel"],
+                     "roofline": {"bound": "valu", "achieved": round(algorithmic_flops(work32, wide32) / (kms32 * 1e-3) / 1e12, 4),
                                   "peak": PEAK_TFLOPS["fp32"], "unit": "TFLOP/s",
-                                  "frac": round(algorithmic_flops(work32) / (kms32 * 1e-3) / 1e12 / PEAK_TFLOPS["fp32"], 5)}},
+                                  "frac": round(algorithmic_flops(work32, wide32) / (kms32 * 1e-3) / 1e12 / PEAK_TFLOPS["fp32"], 5)}},
             "roofline": {"bound": "valu", "achieved": round(achieved, 4), "peak": PEAK_TFLOPS["fp64"], "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_TFLOPS["fp64"], 5), "traffic": traffic,
                          "traffic_source": None if traffic is None else "profiles/traffic.json (stored: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
                                                                         "over this command, not measured in this run)",
-                         "kernel": ("trace_kernel<double, false, 1, false, true, 2>" if cs.counts.get("n_csg_roots") else
-                                    "trace_kernel<double, false, 0, false, true, 4> (+ sum_rays_kernel, ~4 us, inside the same events)"),
+                         "kernel": launched64["kernel"] + " (+ sum_rays_kernel, ~4 us, inside the same events)",
+                         "launch": {k: launched64[k] for k in ("workgroup_threads", "workgroups", "n_units", "n_entries", "feedback_stage")},
                          "kernel_ms": round(kms64, 4),
                          "kernel_ms_source": "HIP events on the launch stream around each of the %d launches of the quoted repetition (mean); "
                                              "kernel_ms <= ms_per_step by construction" % args.steps,
                          "kernel_ms_median_of_all_launches": round(float(np.median(np.concatenate(launches64))), 4),
-                         "algorithmic_flops_per_launch": flops, "algorithmic_bytes_per_launch": algorithmic_bytes(work, 8),
+                         "algorithmic_flops_per_launch": flops, "algorithmic_bytes_per_launch": algorithmic_bytes(work, 8, wide),
                          "algorithmic_bytes_note": "L1-level operand traffic of the counted work (node records, triangle rows, transforms); not HBM "
                                                    "bytes -- not comparable with `traffic`",
                          "work_per_launch": dict(zip(["bvh_node_visits", "triangle_tests", "analytic_leaf_tests", "csg_evals",
-                                                      "shaded_hits", "light_samples", "container_passes", "pattern_evals"], work))},
+                                                      "shaded_hits", "light_samples", "container_passes", "pattern_evals"], work)),
+                         "four_wide_node_visits": wide,
+                         "flop_prices": "SURVEY.md 8d: slab test 24 (4 per four-wide node visit, 2 per binary one), Moller-Trumbore 57, ray -> object 30 + "
+                                        "analytic leaf 40, shade 85, light sample 45, refraction / Schlick 40"},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"], out["parity_on_sample"] = cpu_baseline(scene_world, cam, args.depth, args.cpu_sample, frame_host, ids_host)

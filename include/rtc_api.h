@@ -168,6 +168,8 @@ typedef struct {
     double kernel_ms;    /* trace kernel time measured with HIP events on its stream (host-buffer calls only) */
     int64_t shadow_rays_culled; /* is_shadowed queries answered without a ray: no cell of the light contributes at
                             that hit (light behind the surface), so the result is the ambient term either way */
+    int64_t wide_node_visits; /* RTC_FLAG_COUNT_WORK only: how many of work[0]'s node visits were to the triangle BVH's four-wide
+                            nodes (4 box tests each; the object BVH's binary nodes: 2) */
 } rtc_stats;
 
 typedef struct {
@@ -175,6 +177,22 @@ typedef struct {
     int32_t bvh_nodes, bvh_depth, bvh_max_leaf;
     int64_t device_bytes_fp64, device_bytes_fp32;
 } rtc_scene_info;
+
+/* Which trace kernel variant the last frame of a scene handle was launched as (reporting only: bench.py names the kernel its
+ * roofline line is about; no counterpart in the reference). */
+typedef struct {
+    int32_t precision;         /* 64 | 32 */
+    int32_t csg;               /* 0 = no CSG / perturbed patterns, 1 = with, 2 = with list-free CSG evaluation */
+    int32_t far_camera;        /* rays re-based at the trees' boxes (camera far from the scene) */
+    int32_t replicas;          /* the launch order holds split units whose pixels several lanes trace */
+    int32_t counting_work;     /* RTC_FLAG_COUNT_WORK variant */
+    int32_t waves_per_simd;    /* register budget the variant was built for: 512 / waves registers per lane */
+    int32_t workgroup_threads; /* 64: one wave per workgroup */
+    int32_t workgroups;        /* grid size */
+    int32_t n_units;           /* 8x8 pixel blocks of the frame (or of the tile list) */
+    int32_t n_entries;         /* launch-order entries: units, with the split ones as 4 or 16 parts; = n_units in plain order */
+    int32_t feedback_stage;    /* frames of this view rendered so far on its workspace (0 = plain order, no feedback) */
+} rtc_launch_info;
 
 typedef struct rtc_scene rtc_scene;
 
@@ -215,6 +233,8 @@ int rtc_scene_refit_triangles(rtc_scene *scene, int64_t n_tris, const double *tr
  * copy.  refit != 0 -> refit, else rebuild. */
 int rtc_scene_update_triangles_device(rtc_scene *scene, int64_t n_tris, const double *tri_geom_dev, const double *tri_norm_dev, int refit);
 int rtc_scene_get_info(const rtc_scene *scene, rtc_scene_info *out);
+/* the variant and grid of the most recent launch on this handle (all zero before the first) */
+int rtc_scene_last_launch(const rtc_scene *scene, rtc_launch_info *out);
 
 /* render(cam, world) (renderer.py:753-775).  rgb_out: hsize*vsize*3 doubles in the reference's
  * canvas order [x][y][c] (canvas.py:60); hit_id_out: hsize*vsize leaf ids of the primary hit,
@@ -232,8 +252,9 @@ int rtc_render_tiles(rtc_scene *scene, const rtc_camera *cam, const rtc_render_o
 
 /* Device-pointer form for callers that keep the frame in HBM (bench.py, the multi-GPU gather).
  * tile_ids_dev == NULL renders the whole frame into the [x][y][c] layout; otherwise the
-* compact tile layout above.  rays_dev (may be NULL) is ADDED to and must hold 13 int64: [0..3] ray
- * counts, [4..11] the work counters of rtc_stats (RTC_FLAG_COUNT_WORK only), [12] shadow rays culled.  Asynchronous on
+* compact tile layout above.  rays_dev (may be NULL) is ADDED to and must hold 13 int64 (14 with RTC_FLAG_COUNT_WORK): [0..3] ray
+ * counts, [4..11] the work counters of rtc_stats (RTC_FLAG_COUNT_WORK only), [12] shadow rays culled, [13] rtc_stats::wide_node_visits
+ * (RTC_FLAG_COUNT_WORK only).  Asynchronous on
  * `stream` (a hipStream_t, NULL = default stream).  A scene handle is immutable while frames are rendered and
  * may be rendered from several host threads at once, one stream per call: every call takes a workspace of its own
  * (the launch-order buffers of RTC_FLAG_NO_FEEDBACK's comment) from the handle and gives it back when its stream

@@ -50,7 +50,8 @@ class RenderOpts(C.Structure):
 
 
 class Stats(C.Structure):
-    _fields_ = [("rays", C.c_int64 * 4), ("work", C.c_int64 * 8), ("kernel_ms", C.c_double), ("shadow_rays_culled", C.c_int64)]
+    _fields_ = [("rays", C.c_int64 * 4), ("work", C.c_int64 * 8), ("kernel_ms", C.c_double), ("shadow_rays_culled", C.c_int64),
+                ("wide_node_visits", C.c_int64)]
 
 
 class SceneInfo(C.Structure):
@@ -58,7 +59,12 @@ class SceneInfo(C.Structure):
                 ("bvh_max_leaf", C.c_int32), ("device_bytes_fp64", C.c_int64), ("device_bytes_fp32", C.c_int64)]
 
 
-EXPORTS = ["rtc_version", "rtc_device_count", "rtc_last_error", "rtc_scene_create", "rtc_scene_destroy",
+class LaunchInfo(C.Structure):
+    _fields_ = [(k, C.c_int32) for k in ("precision", "csg", "far_camera", "replicas", "counting_work", "waves_per_simd",
+                                          "workgroup_threads", "workgroups", "n_units", "n_entries", "feedback_stage")]
+
+
+EXPORTS = ["rtc_scene_last_launch", "rtc_version", "rtc_device_count", "rtc_last_error", "rtc_scene_create", "rtc_scene_destroy",
            "rtc_scene_get_info", "rtc_render", "rtc_render_tiles", "rtc_render_device", "rtc_render_device_noalloc", "rtc_quantize_device",
            "rtc_scatter_tiles_device", "rtc_scatter_id_tiles_device", "rtc_frame_max_device", "rtc_ppm_body_device", "rtc_ppm_size", "rtc_render_ppm",
            "rtc_scene_build_bvh_device", "rtc_scene_update_triangles", "rtc_scene_refit_triangles", "rtc_scene_update_triangles_device",
@@ -103,6 +109,7 @@ def lib():
         L.rtc_scene_destroy.argtypes = [_P]
         L.rtc_scene_destroy.restype = None
         L.rtc_scene_get_info.argtypes = [_P, C.POINTER(SceneInfo)]
+        L.rtc_scene_last_launch.argtypes = [_P, C.POINTER(LaunchInfo)]
         L.rtc_render.argtypes = [_P, C.POINTER(CameraDesc), C.POINTER(RenderOpts), _P, _P, C.POINTER(Stats)]
         L.rtc_render_tiles.argtypes = [_P, C.POINTER(CameraDesc), C.POINTER(RenderOpts), C.c_int32, _P, _P, _P,
                                        C.POINTER(Stats)]
@@ -272,6 +279,15 @@ class Scene(object):
         _check(lib().rtc_scene_get_info(self.handle, C.byref(out)))
         return {k: getattr(out, k) for k, _ in SceneInfo._fields_}
 
+    def last_launch(self):
+        """Which trace kernel variant the most recent frame of this handle was launched as, and its grid (reporting only)."""
+        out = LaunchInfo()
+        _check(lib().rtc_scene_last_launch(self.handle, C.byref(out)))
+        d = {k: getattr(out, k) for k, _ in LaunchInfo._fields_}
+        d["kernel"] = "trace_kernel<%s, %s, %d, %s, %s, %d>" % ("double" if d["precision"] == 64 else "float", "true" if d["counting_work"] else "false", d["csg"],
+                                                               "true" if d["far_camera"] else "false", "true" if d["replicas"] else "false", d["waves_per_simd"])
+        return d
+
     def render(self, cam, precision="fp64", max_depth=5, want_ids=False, stats=None, shade_eps=0.0, seed=0,
                count_work=False, feedback=True):
         """-> (rgb (hsize, vsize, 3) f64, ids (hsize, vsize) i32 or None)."""
@@ -336,6 +352,7 @@ def _fill_stats(stats, st):
         stats["work"] = [int(v) for v in st.work]
         stats["kernel_ms"] = float(st.kernel_ms)
         stats["shadow_rays_culled"] = int(st.shadow_rays_culled)
+        stats["wide_node_visits"] = int(st.wide_node_visits)
 
 
 def tiles_for(hsize, vsize, tile_size=32):

@@ -359,6 +359,7 @@ struct rtc_scene {
     DeviceArena tbvh_mem;
     // for refits (same arena): triangle row at each BVH position, parent link of each node, arrival counters
     int32_t* d_tb_row = nullptr; int32_t* d_tparent = nullptr; uint32_t* d_tarrived = nullptr;
+    rtc_launch_info last_launch{};      // what the most recent launch was (rtc_scene_last_launch; reporting only)
     int n_tnodes4 = 0;       // records in d64.tnodes4 (host-built: compact; GPU-built: one per binary node, unused ones empty)
     double max_abs = 0;      // largest coordinate of any box the scene's trees were padded for (RTC_PAD_OF_EXTENT)
     // device-side frame, hit ids, counters and tile list of the host-buffer entry points, kept between calls
@@ -914,8 +915,8 @@ int debug_sync(hipStream_t stream, const char* what, unsigned grid_x, const rtc:
 }
 
 // the trace kernel variant for (precision, counting, CSG / perturbed patterns) on `grid` workgroups
-void launch_trace(const rtc_scene* scene, const rtc_camera* cam, const rtc::DFrame& F, dim3 grid, int precision, bool prof, double eps, double eps_rel,
-                  hipStream_t stream, bool two_waves = false) {
+void launch_trace(rtc_scene* scene, const rtc_camera* cam, const rtc::DFrame& F, dim3 grid, int precision, bool prof, double eps, double eps_rel,
+                  hipStream_t stream, bool two_waves = false, int feedback_stage = 0) {
     const bool csg = scene->has_csg;
     // `grid` counts RTC_BLOCK-thread blocks (4 entries of the launch order each); the variants without CSG run one entry per workgroup
     const dim3 block(csg ? RTC_BLOCK_CSG : RTC_BLOCK_PLAIN);
@@ -924,6 +925,13 @@ void launch_trace(const rtc_scene* scene, const rtc_camera* cam, const rtc::DFra
     const double far_origin = scene->d64.far_origin;
     const bool far_cam = std::fabs(cam->inv_transform[3]) > far_origin || std::fabs(cam->inv_transform[7]) > far_origin || std::fabs(cam->inv_transform[11]) > far_origin;
     const bool repl = F.replicas != 0 && !prof;
+    {
+        rtc_launch_info& L = scene->last_launch;
+        L.precision = precision; L.csg = !csg ? 0 : scene->has_csg_stream ? 2 : 1; L.far_camera = far_cam; L.replicas = repl; L.counting_work = prof;
+        L.waves_per_simd = csg ? 2 : precision == 64 ? ((two_waves && !prof) ? 2 : RTC_WAVES_F64) : RTC_WAVES_F32;
+        L.workgroup_threads = (int32_t)block.x; L.workgroups = (int32_t)grid.x; L.n_units = F.n_units; L.n_entries = F.order ? F.n_entries : F.n_units;
+        L.feedback_stage = feedback_stage;
+    }
 #define RTC_LAUNCH_W(R, PROF, CSG, FAR, REPL, W, SC) \
     hipLaunchKernelGGL((rtc::trace_kernel<R, PROF, CSG, FAR, REPL, W>), grid, block, 0, stream, SC, make_camera<R>(*cam), F, (R)eps, (R)eps_rel)
 #define RTC_LAUNCH_K(R, PROF, CSG, FAR, REPL, SC) RTC_LAUNCH_W(R, PROF, CSG, FAR, REPL, RTC_WAVES_OF(R, CSG), SC)
@@ -1073,7 +1081,7 @@ int launch(rtc_scene* scene, const rtc_camera* cam, const rtc_render_opts* opts,
     if (ray_parts && (long long)grid.x * (RTC_BLOCK / 64) > n_entries)      // every wave of the grid has a slot (the kernel's own guard never fires)
         return fail(RTC_ERR_HIP, "internal: %lld waves for %lld ray count slots", (long long)grid.x * (RTC_BLOCK / 64), n_entries);
     if (timing >= 0) HIP_TRY(hipEventRecord(ws->tune_ev[timing], stream));
-    launch_trace(scene, cam, F, grid, precision, work_dev != nullptr, eps, eps_rel, stream, two_waves);
+    launch_trace(scene, cam, F, grid, precision, work_dev != nullptr, eps, eps_rel, stream, two_waves, (ws && feedback) ? ws->fb_age : 0);
     if (int rc = debug_sync(stream, "trace_kernel", grid.x, F)) return rc;
     if (ray_parts) {
         const int n_waves = (int)std::min<long long>((long long)grid.x * (RTC_BLOCK / 64), n_entries);
@@ -1128,7 +1136,7 @@ int render_host(rtc_scene* scene, const rtc_camera* cam, const rtc_render_opts* 
     if (int rc = grow(scene->out_rgb, scene->out_rgb_px, n_px, 3 * sizeof(double))) return rc;
     if (hit_id_out) if (int rc = grow(scene->out_id, scene->out_id_px, n_px, sizeof(int32_t))) return rc;
     if (tiled) if (int rc = grow(scene->out_tiles, scene->out_tiles_n, (size_t)n_tiles, sizeof(int32_t))) return rc;
-    if (!scene->out_rays) HIP_TRY(hipMalloc((void**)&scene->out_rays, 13 * sizeof(int64_t)));
+    if (!scene->out_rays) HIP_TRY(hipMalloc((void**)&scene->out_rays, 14 * sizeof(int64_t)));
     if (!scene->out_e0) HIP_TRY(hipEventCreate(&scene->out_e0));
     if (!scene->out_e1) HIP_TRY(hipEventCreate(&scene->out_e1));
     double* d_rgb = scene->out_rgb; int32_t* d_id = hit_id_out ? scene->out_id : nullptr; int64_t* d_rays = scene->out_rays;
@@ -1139,7 +1147,7 @@ int render_host(rtc_scene* scene, const rtc_camera* cam, const rtc_render_opts* 
     if (tiled) TRY_C(hipMemsetAsync(d_rgb, 0, n_px * 3 * sizeof(double), nullptr));
     if (hit_id_out) TRY_C(hipMemsetAsync(d_id, 0xFF, n_px * sizeof(int32_t), nullptr));
     const bool want_work = stats_out && opts && (opts->flags & RTC_FLAG_COUNT_WORK);
-    TRY_C(hipMemsetAsync(d_rays, 0, 13 * sizeof(int64_t), nullptr));
+    TRY_C(hipMemsetAsync(d_rays, 0, 14 * sizeof(int64_t), nullptr));
     if (tiled) TRY_C(hipMemcpy(d_tiles, tile_ids, (size_t)n_tiles * sizeof(int32_t), hipMemcpyHostToDevice));
     TRY_C(hipEventRecord(e0, nullptr));
     rc = launch(scene, cam, opts, n_tiles, d_tiles, d_rgb, d_id, d_rays, want_work ? d_rays + 4 : nullptr, nullptr);
@@ -1148,12 +1156,12 @@ int render_host(rtc_scene* scene, const rtc_camera* cam, const rtc_render_opts* 
     TRY_C(hipMemcpy(rgb_out, d_rgb, n_px * 3 * sizeof(double), hipMemcpyDeviceToHost));     // null stream: after the kernel
     if (hit_id_out) TRY_C(hipMemcpy(hit_id_out, d_id, n_px * sizeof(int32_t), hipMemcpyDeviceToHost));
     if (stats_out) {
-        int64_t host_rays[13];
+        int64_t host_rays[14];
         TRY_C(hipMemcpy(host_rays, d_rays, sizeof(host_rays), hipMemcpyDeviceToHost));
         float ms = 0;
         TRY_C(hipEventElapsedTime(&ms, e0, e1));
         memcpy(stats_out->rays, host_rays, 4 * sizeof(int64_t));
-        if (want_work) memcpy(stats_out->work, host_rays + 4, 8 * sizeof(int64_t));
+        if (want_work) { memcpy(stats_out->work, host_rays + 4, 8 * sizeof(int64_t)); stats_out->wide_node_visits = host_rays[13]; }
         stats_out->shadow_rays_culled = host_rays[12];
         stats_out->kernel_ms = ms;
     }
@@ -1291,6 +1299,12 @@ int rtc_scene_get_info(const rtc_scene* scene, rtc_scene_info* out) {
     out->bvh_nodes = scene->bvh_nodes; out->bvh_depth = scene->bvh_depth; out->bvh_max_leaf = scene->bvh_max_leaf;
     out->device_bytes_fp64 = (int64_t)(scene->shared.bytes + scene->mem64.bytes);
     out->device_bytes_fp32 = (int64_t)(scene->shared.bytes + scene->mem32.bytes);
+    return 0;
+}
+
+int rtc_scene_last_launch(const rtc_scene* scene, rtc_launch_info* out) {
+    if (!scene || !out) return fail(RTC_ERR_INVALID, "null argument");
+    *out = scene->last_launch;
     return 0;
 }
 
@@ -1483,13 +1497,13 @@ int rtc_render_ppm(rtc_scene* scene, const rtc_camera* cam, const rtc_render_opt
         HIP_TRY(hipMalloc((void**)&scene->out_ppm, total + 2 * sizeof(double)));
         scene->out_ppm_bytes = total + sizeof(double);
     }
-    if (!scene->out_rays) HIP_TRY(hipMalloc((void**)&scene->out_rays, 13 * sizeof(int64_t)));
+    if (!scene->out_rays) HIP_TRY(hipMalloc((void**)&scene->out_rays, 14 * sizeof(int64_t)));
     double* d_rgb = scene->out_rgb; int64_t* d_rays = scene->out_rays;
     double* d_max = reinterpret_cast<double*>(scene->out_ppm);             // 8 bytes in front of the file
     uint8_t* d_out = scene->out_ppm + sizeof(double);
     int rc = 0;
 #define TRY_C(expr) HIP_TRY(expr)
-    TRY_C(hipMemsetAsync(d_rays, 0, 13 * sizeof(int64_t), nullptr));
+    TRY_C(hipMemsetAsync(d_rays, 0, 14 * sizeof(int64_t), nullptr));
     const bool want_work = stats_out && opts && (opts->flags & RTC_FLAG_COUNT_WORK);
     rc = launch(scene, cam, opts, 0, nullptr, d_rgb, nullptr, d_rays, want_work ? d_rays + 4 : nullptr, nullptr);
     if (rc) return rc;
@@ -1507,6 +1521,7 @@ int rtc_render_ppm(rtc_scene* scene, const rtc_camera* cam, const rtc_render_opt
     if (stats_out) {
         TRY_C(hipMemcpy(stats_out->rays, d_rays, 4 * sizeof(int64_t), hipMemcpyDeviceToHost));
         if (want_work) TRY_C(hipMemcpy(stats_out->work, d_rays + 4, 8 * sizeof(int64_t), hipMemcpyDeviceToHost));
+        if (want_work) TRY_C(hipMemcpy(&stats_out->wide_node_visits, d_rays + 13, sizeof(int64_t), hipMemcpyDeviceToHost));
         TRY_C(hipMemcpy(&stats_out->shadow_rays_culled, d_rays + 12, sizeof(int64_t), hipMemcpyDeviceToHost));
     }
 #undef TRY_C

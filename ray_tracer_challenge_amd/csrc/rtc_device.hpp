@@ -235,7 +235,9 @@ __device__ __forceinline__ long long wave_unit(const DFrame& F, bool& lane_on, i
 // c: rays traced (primary, shadow, reflection, refraction).  w (PROF builds only): BVH node
 // visits (2 box tests each), triangle tests, analytic leaf tests, CSG root evaluations, shaded
 // hits, light samples shaded, container passes, pattern-node evaluations.
-enum { W_NODE = 0, W_TRI = 1, W_LEAF = 2, W_CSG = 3, W_SHADE = 4, W_LIGHT = 5, W_CONTAINER = 6, W_PATTERN = 7, W_COUNT = 8 };
+// W_NODE4: how many of the W_NODE visits were to four-wide (triangle BVH) nodes, 4 box tests each (kept outside rtc_stats::work:
+// rays_dev[13]).
+enum { W_NODE = 0, W_TRI = 1, W_LEAF = 2, W_CSG = 3, W_SHADE = 4, W_LIGHT = 5, W_CONTAINER = 6, W_PATTERN = 7, W_NODE4 = 8, W_COUNT = 9 };
 // CSG = false compiles the CSG branches out of every visitor (scenes without CSG objects then
 // carry none of its per-lane hit lists) and the Perlin noise of perturbed patterns out of the pattern
 // interpreter: the host picks the CSG = true variants for scenes that have either.
@@ -677,6 +679,7 @@ __device__ __forceinline__ bool traverse_bvh4(const DScene<R>& S, const Ray<R>& 
     while (true) {
         if (node >= 0) {
             vis.cnt.work(W_NODE);
+            vis.cnt.work(W_NODE4);
             float b[24];
             int c[4];
             const int node0 = __builtin_amdgcn_readfirstlane(node);
@@ -1635,7 +1638,7 @@ __device__ __forceinline__ void flush_counters(Counters<PROF, CSG, FAR, STREAM, 
         for (int k = 0; k < W_COUNT; k++) {
             unsigned int v = cnt.w[k];
             for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-            if ((threadIdx.x & 63) == 0 && v) atomicAdd(F.work + k, (unsigned long long)v);
+            if ((threadIdx.x & 63) == 0 && v) atomicAdd(k < 8 ? F.work + k : F.rays + 13, (unsigned long long)v);      // [4..11] = rtc_stats::work, [13] = wide node visits
         }
     }
 }
