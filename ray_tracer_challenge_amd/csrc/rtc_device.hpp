@@ -1584,6 +1584,29 @@ __device__ __forceinline__ V3<R> trace_tree(const DScene<R>& S, Ray<R> ray, V3<R
     return color;
 }
 
+// Can a camera ray meet anything at all?  The conservative fp32 slab test of traverse_bvh against the boxes of the two trees
+// (a scene with unbounded things -- a floor plane -- always can).  A block of sky pixels then skips the trace code altogether:
+// its colour is the reference's black for a ray that hits nothing (renderer.py:606-611), and it never executes the register
+// spills at the head of that code -- which every wave of a 1080p dragons frame used to write to scratch, sky waves (60 % of
+// them) included: two thirds of the frame's HBM write traffic.  Not for the far-camera variants (the fp32 test is relative to
+// the ray's origin; their rays are re-based inside the walks).
+template <class R> __device__ __forceinline__ bool may_hit_box(const Ray<R>& ray, const float* b) {
+    float ix = 1.0f / (float)ray.d.x, iy = 1.0f / (float)ray.d.y, iz = 1.0f / (float)ray.d.z;
+    if (!(fabsf(ix) <= 1e30f)) ix = copysignf(1e30f, (float)ray.d.x);
+    if (!(fabsf(iy) <= 1e30f)) iy = copysignf(1e30f, (float)ray.d.y);
+    if (!(fabsf(iz) <= 1e30f)) iz = copysignf(1e30f, (float)ray.d.z);
+    const float ox = -(float)ray.o.x * ix, oy = -(float)ray.o.y * iy, oz = -(float)ray.o.z * iz;
+    const float x0 = fmaf(b[0], ix, ox), x1 = fmaf(b[3], ix, ox), y0 = fmaf(b[1], iy, oy), y1 = fmaf(b[4], iy, oy), z0 = fmaf(b[2], iz, oz), z1 = fmaf(b[5], iz, oz);
+    float n = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
+    float f = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
+    n -= fabsf(n) * 1e-5f; f += fabsf(f) * 1e-5f;
+    return n <= f && f >= 0.0f;
+}
+template <class R, class CNT> __device__ __forceinline__ bool may_hit_scene(const DScene<R>& S, const Ray<R>& ray) {
+    if (CNT::kFar || S.n_unbounded > 0) return true;
+    return (S.n_bvh_nodes > 0 && may_hit_box(ray, S.obox)) || (S.n_tnodes > 0 && may_hit_box(ray, S.tbox));
+}
+
 // color_at for one primary ray (the single-kernel form)
 template <class R, class CNT>
 __device__ __forceinline__ V3<R> trace_pixel(const DScene<R>& S, Ray<R> primary, int max_depth, R shade_eps, R shade_eps_rel, int* stack,

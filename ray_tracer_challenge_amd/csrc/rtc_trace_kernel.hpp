@@ -33,8 +33,10 @@ __global__ __launch_bounds__((CSG > 0) ? RTC_BLOCK_CSG : RTC_BLOCK_PLAIN, WAVES)
 #ifdef RTC_TIMELINE
         long long tl_start = wall_clock64();
 #endif
-        rtc::V3<R> c = rtc::trace_pixel(S, ray, F.max_depth, shade_eps, shade_eps_rel, stack, cnt, F.seed,
-                                        (uint32_t)(y * cam.hsize + x), hit_leaf);
+        rtc::V3<R> c = rtc::mk<R>(0, 0, 0);
+        hit_leaf = -1;
+        if (rtc::may_hit_scene<R, CNT>(S, ray))          // (a ray that meets neither tree's box is black: the sky waves end here)
+            c = rtc::trace_pixel(S, ray, F.max_depth, shade_eps, shade_eps_rel, stack, cnt, F.seed, (uint32_t)(y * cam.hsize + x), hit_leaf);
 #ifdef RTC_TIMELINE   /* development build only (tools/timeline.py): start/end ticks (100 MHz) instead of the colour */
         c.x = (R)(double)(tl_start & 0xFFFFFFFFFFLL); c.y = (R)(double)(wall_clock64() & 0xFFFFFFFFFFLL); c.z = R(0);
 #endif
