@@ -55,6 +55,12 @@
 #ifndef RTC_BVH4_SORT_ANYHIT
 #define RTC_BVH4_SORT_ANYHIT 0   // development: 1 = shadow rays and container passes sort the children of a four-wide node like nearest-hit queries do
 #endif
+#ifndef RTC_NODE_SPLIT
+#define RTC_NODE_SPLIT 1      // development: 0 = one copy of a node visit's arithmetic behind both ways a record is fetched
+#endif
+#ifndef RTC_TRI_SPLIT
+#define RTC_TRI_SPLIT 0       // development: 1 = the same split for triangle rows (measured: teapot -4 %, dragons 1080p fp64 +12 %: off)
+#endif
 #ifndef RTC_BVH_STACK
 #define RTC_BVH_STACK 32      // per-lane traversal stack entries, in LDS
 #endif
@@ -355,36 +361,8 @@ template <class T> __device__ __forceinline__ const T* uniform_ptr(const T* p) {
     return reinterpret_cast<const T*>(((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(a >> 32)) << 32) |
                                       (unsigned int)__builtin_amdgcn_readfirstlane((int)a));
 }
-// shapes.py:812-830 / 860-878 on world-space data; g = p1, e1, e2, det_eps
-template <class R> __device__ __forceinline__ bool tri_hit(const R* __restrict__ g, const Ray<R>& r, R& t, R& u, R& v, bool uniform = false) {
-    // `uniform`: every active lane of the wave tests this same row (traverse_bvh found them at the same leaf): the row
-    // comes through the scalar unit, like the node records
-    R row[10];
-    if (uniform) {
-        const R* g0 = uniform_ptr(g);
-        if (sizeof(R) == 8) {
-            typedef double d8v __attribute__((ext_vector_type(8)));
-            typedef double d2v __attribute__((ext_vector_type(2)));
-            d8v a; d2v b;
-            // early-clobber outputs: both loads read the address pair, which must not be handed out as (part of) a destination
-            asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx4 %1, %2, 0x40\n\ts_waitcnt lgkmcnt(0)" : "=&s"(a), "=&s"(b) : "s"(g0) : "memory");
-#pragma unroll
-            for (int k = 0; k < 8; k++) row[k] = (R)a[k];
-            row[8] = (R)b[0]; row[9] = (R)b[1];
-        } else {
-            typedef float f8v __attribute__((ext_vector_type(8)));
-            typedef float f2v __attribute__((ext_vector_type(2)));
-            f8v a; f2v b;
-            asm volatile("s_load_dwordx8 %0, %2, 0x0\n\ts_load_dwordx2 %1, %2, 0x20\n\ts_waitcnt lgkmcnt(0)" : "=&s"(a), "=&s"(b) : "s"(g0) : "memory");
-#pragma unroll
-            for (int k = 0; k < 8; k++) row[k] = (R)a[k];
-            row[8] = (R)b[0]; row[9] = (R)b[1];
-        }
-    } else {
-#pragma unroll
-        for (int k = 0; k < 10; k++) row[k] = g[k];
-    }
-    g = row;
+// shapes.py:812-830 / 860-878 on world-space data; row = p1, e1, e2, det_eps
+template <class R, class ROW> __device__ __forceinline__ bool tri_test(const ROW& g, const Ray<R>& r, R& t, R& u, R& v) {
     V3<R> p1 = mk<R>(g[0], g[1], g[2]), e1 = mk<R>(g[3], g[4], g[5]), e2 = mk<R>(g[6], g[7], g[8]);
     V3<R> dir_cross_e2 = cross(r.d, e2);
     R det = dot(e1, dir_cross_e2);
@@ -398,6 +376,39 @@ template <class R> __device__ __forceinline__ bool tri_hit(const R* __restrict__
     if (v < R(0) || (u + v) > R(1)) return false;
     t = f * dot(e2, origin_cross_e1);
     return true;
+}
+template <class R> struct TriRow { R v[10]; __device__ __forceinline__ R operator[](int k) const { return v[k]; } };
+template <class R> __device__ __forceinline__ bool tri_hit(const R* __restrict__ g, const Ray<R>& r, R& t, R& u, R& v, bool uniform = false) {
+    // `uniform`: every active lane of the wave tests this same row (traverse_bvh4 found them at the same leaf): the row
+    // comes through the scalar unit, like the node records.  (RTC_TRI_SPLIT: a copy of the arithmetic of its own for the
+    // scalar row, reading it from scalar registers, as the node visits have -- measured slower on the dragons in fp64, off.)
+    TriRow<R> row;
+    if (uniform) {
+        const R* g0 = uniform_ptr(g);
+        if (sizeof(R) == 8) {
+            typedef double d8v __attribute__((ext_vector_type(8)));
+            typedef double d2v __attribute__((ext_vector_type(2)));
+            d8v a; d2v b;
+            // early-clobber outputs: both loads read the address pair, which must not be handed out as (part of) a destination
+            asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx4 %1, %2, 0x40\n\ts_waitcnt lgkmcnt(0)" : "=&s"(a), "=&s"(b) : "s"(g0) : "memory");
+#pragma unroll
+            for (int k = 0; k < 8; k++) row.v[k] = (R)a[k];
+            row.v[8] = (R)b[0]; row.v[9] = (R)b[1];
+        } else {
+            typedef float f8v __attribute__((ext_vector_type(8)));
+            typedef float f2v __attribute__((ext_vector_type(2)));
+            f8v a; f2v b;
+            asm volatile("s_load_dwordx8 %0, %2, 0x0\n\ts_load_dwordx2 %1, %2, 0x20\n\ts_waitcnt lgkmcnt(0)" : "=&s"(a), "=&s"(b) : "s"(g0) : "memory");
+#pragma unroll
+            for (int k = 0; k < 8; k++) row.v[k] = (R)a[k];
+            row.v[8] = (R)b[0]; row.v[9] = (R)b[1];
+        }
+        if (RTC_TRI_SPLIT) return tri_test(row, r, t, u, v);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 10; k++) row.v[k] = g[k];
+    }
+    return tri_test(row, r, t, u, v);
 }
 
 // hits of one leaf (world-space ray in, t's out, unsorted); u,v only for triangles
@@ -541,6 +552,76 @@ struct PrimCode {
         : kind((int)((uint32_t)c >> 28)), idx((int)((uint32_t)c & 0x07FFFFFFu)), noshadow((((uint32_t)c >> 27) & 1u) != 0) {}
 };
 
+// What the box tests of a walk need of the ray: reciprocal direction, -origin / direction, the near bound (fp32, see traverse_bvh)
+struct SlabRay { float ix, iy, iz, ox, oy, oz, tlo32; };
+// entry and exit distance of the ray in one box (lo xyz, hi xyz), with the outward slack of traverse_bvh
+__device__ __forceinline__ void slab_test(float lx, float ly, float lz, float hx, float hy, float hz, const SlabRay& s, float& n, float& f) {
+    const float x0 = fmaf(lx, s.ix, s.ox), x1 = fmaf(hx, s.ix, s.ox);
+    const float y0 = fmaf(ly, s.iy, s.oy), y1 = fmaf(hy, s.iy, s.oy);
+    const float z0 = fmaf(lz, s.iz, s.oz), z1 = fmaf(hz, s.iz, s.oz);
+    n = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
+    f = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
+    n -= fabsf(n) * 1e-5f;
+    f += fabsf(f) * 1e-5f;
+}
+// One visit to a binary node: both child boxes tested, the nearer child that is hit returned (RTC_EMPTY_CHILD: none), the
+// other pushed.  The record's 12 box values and two child references are taken wherever they arrived: each way of fetching
+// a record (vector loads; one scalar load when the wave is at one node) calls its own copy of this, so that the scalar one
+// reads its operands from scalar registers -- merged behind the fetch, every scalar record was first moved to vector
+// registers (16 v_mov a binary visit, 28 a four-wide one).
+struct NodeRec2 { float b[12]; int c0, c1; };
+template <int STRIDE> __device__ __forceinline__ int bvh2_visit(const NodeRec2& r, const SlabRay& s, float lim, int* stack, int& sp) {
+    float n0, f0, n1, f1;
+    slab_test(r.b[0], r.b[1], r.b[2], r.b[3], r.b[4], r.b[5], s, n0, f0);
+    slab_test(r.b[6], r.b[7], r.b[8], r.b[9], r.b[10], r.b[11], s, n1, f1);
+    // (`&`, not `&&`: the comparisons are data, not control flow -- with `&&` the compiler put every box test under a branch of its own)
+    const bool h0 = (r.c0 != RTC_EMPTY_CHILD) & (n0 <= f0) & (f0 >= s.tlo32) & (n0 <= lim);
+    const bool h1 = (r.c1 != RTC_EMPTY_CHILD) & (n1 <= f1) & (f1 >= s.tlo32) & (n1 <= lim);
+    if (h0 && h1) {
+        const bool swap = n1 < n0;
+        stack[sp * STRIDE] = swap ? r.c0 : r.c1; sp++;
+        return swap ? r.c1 : r.c0;
+    }
+    return h0 ? r.c0 : h1 ? r.c1 : RTC_EMPTY_CHILD;
+}
+// One visit to a four-wide node.  UNORDERED (any-hit queries, passes with a fixed far bound): a child that is hit is
+// entered, the others pushed.  Otherwise the children that are hit are visited nearest first: their entry distances
+// (clamped at 0, the child's slot in the two lowest mantissa bits) and references are sorted together by a five-exchange
+// network -- branch-free; picking the references by slot after sorting the keys alone compiled to nested branches -- the
+// nearest is returned, the others pushed farthest first.
+struct NodeRec4 { float b[24]; int c[4]; };
+template <int STRIDE, bool UNORDERED> __device__ __forceinline__ int bvh4_visit(const NodeRec4& r, const SlabRay& s, float lim, int* stack, int& sp) {
+    unsigned int key[4];
+    bool hit[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        float n, f;
+        slab_test(r.b[6 * k], r.b[6 * k + 1], r.b[6 * k + 2], r.b[6 * k + 3], r.b[6 * k + 4], r.b[6 * k + 5], s, n, f);
+        hit[k] = (r.c[k] != RTC_EMPTY_CHILD) & (n <= f) & (f >= s.tlo32) & (n <= lim);
+        key[k] = hit[k] ? ((__float_as_uint(fmaxf(n, 0.0f)) & ~3u) | (unsigned)k) : 0xFFFFFFFFu;
+    }
+    if (UNORDERED) {
+        int next = RTC_EMPTY_CHILD;
+#pragma unroll
+        for (int k = 3; k >= 0; k--)
+            if (hit[k]) {
+                if (next != RTC_EMPTY_CHILD) { stack[sp * STRIDE] = next; sp++; }
+                next = r.c[k];
+            }
+        return next;
+    }
+    int ref[4] = {r.c[0], r.c[1], r.c[2], r.c[3]};
+#define RTC_CE(i, j) { const bool sw_ = key[j] < key[i]; const unsigned int ki_ = key[i], kj_ = key[j]; const int ri_ = ref[i], rj_ = ref[j]; \
+                       key[i] = sw_ ? kj_ : ki_; key[j] = sw_ ? ki_ : kj_; ref[i] = sw_ ? rj_ : ri_; ref[j] = sw_ ? ri_ : rj_; }
+    RTC_CE(0, 1) RTC_CE(2, 3) RTC_CE(0, 2) RTC_CE(1, 3) RTC_CE(1, 2)
+#undef RTC_CE
+    if (key[0] == 0xFFFFFFFFu) return RTC_EMPTY_CHILD;
+    if (key[3] != 0xFFFFFFFFu) { stack[sp * STRIDE] = ref[3]; sp++; }
+    if (key[2] != 0xFFFFFFFFu) { stack[sp * STRIDE] = ref[2]; sp++; }
+    if (key[1] != 0xFFFFFFFFu) { stack[sp * STRIDE] = ref[1]; sp++; }
+    return ref[0];
+}
+
 // Visitor V: bool prim(code) -> true = stop the traversal; R limit() = current far bound.
 // Boxes are visited when their slab interval overlaps (tlo, limit()).
 // The OBJECT BVH (binary; leaves hold prim codes -> vis.prim); the triangle BVH is walked four-wide, traverse_bvh4.
@@ -589,49 +670,36 @@ __device__ __forceinline__ bool traverse_bvh(const DScene<R>& S, const Ray<R>& r
     while (true) {
         if (node >= 0) {
             vis.cnt.work(W_NODE);
+#ifdef RTC_LANE_STATS_DETAIL   /* one-off measurement (tools/lane_stats.py): pattern_evals = wave-uniform binary visits */
+            if (__builtin_amdgcn_ballot_w64(node != __builtin_amdgcn_readfirstlane(node)) == 0ull) vis.cnt.work(W_PATTERN);
+#endif
             // every lane of the wave at the same node (the top of the tree, for the rays of one pixel block): the record
             // comes through the scalar unit (one 64-byte scalar load) and leaves the vector memory pipe alone
-            float4 q0, q1, q2, q3;
+            float lim = (float)vis.limit();
+            if (V::Cnt::kFar) lim -= base32;                    // (float)limit is off by 6e-8 |limit| <= 6e-8 (|base| + |lim|): lim_pad + the relative slack
+            lim += fabsf(lim) * 1e-6f;
+            if (V::Cnt::kFar) lim += lim_pad;
+            const SlabRay sr = {ix, iy, iz, ox, oy, oz, tlo32};
+            int next;
+            NodeRec2 r;
             const int node0 = __builtin_amdgcn_readfirstlane(node);
             if (__builtin_amdgcn_ballot_w64(node != node0) == 0ull) {
                 typedef float f16v __attribute__((ext_vector_type(16)));
                 f16v rec;
                 const BvhNode* p0 = uniform_ptr(nodes + node0);
                 asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rec) : "s"(p0) : "memory");
-                q0 = make_float4(rec[0], rec[1], rec[2], rec[3]); q1 = make_float4(rec[4], rec[5], rec[6], rec[7]);
-                q2 = make_float4(rec[8], rec[9], rec[10], rec[11]); q3 = make_float4(rec[12], rec[13], rec[14], rec[15]);
+                const NodeRec2 rs = {{rec[0], rec[1], rec[2], rec[3], rec[4], rec[5], rec[6], rec[7], rec[8], rec[9], rec[10], rec[11]},
+                                     __float_as_int(rec[12]), __float_as_int(rec[13])};
+                if (RTC_NODE_SPLIT) next = bvh2_visit<kStride>(rs, sr, lim, stack, sp); else r = rs;
             } else {
                 const float4* q = reinterpret_cast<const float4*>(nodes + node);
-                q0 = q[0]; q1 = q[1]; q2 = q[2]; q3 = q[3];
+                const float4 q0 = q[0], q1 = q[1], q2 = q[2];
+                const float2 q3 = *reinterpret_cast<const float2*>(q + 3);
+                const NodeRec2 rv = {{q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w}, __float_as_int(q3.x), __float_as_int(q3.y)};
+                if (RTC_NODE_SPLIT) next = bvh2_visit<kStride>(rv, sr, lim, stack, sp); else r = rv;
             }
-            const float b[12] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w};
-            int c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y);
-            float near[2], far[2];
-#pragma unroll
-            for (int k = 0; k < 2; k++) {
-                const float* lo = b + 6 * k; const float* hi = lo + 3;
-                float x0 = fmaf(lo[0], ix, ox), x1 = fmaf(hi[0], ix, ox);
-                float y0 = fmaf(lo[1], iy, oy), y1 = fmaf(hi[1], iy, oy);
-                float z0 = fmaf(lo[2], iz, oz), z1 = fmaf(hi[2], iz, oz);
-                float n = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
-                float f = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
-                near[k] = n - fabsf(n) * 1e-5f;
-                far[k] = f + fabsf(f) * 1e-5f;
-            }
-            float lim = (float)vis.limit();
-            if (V::Cnt::kFar) lim -= base32;                    // (float)limit is off by 6e-8 |limit| <= 6e-8 (|base| + |lim|): lim_pad + the relative slack
-            lim += fabsf(lim) * 1e-6f;
-            if (V::Cnt::kFar) lim += lim_pad;
-            bool h0 = c0 != RTC_EMPTY_CHILD && near[0] <= far[0] && far[0] >= tlo32 && near[0] <= lim;
-            bool h1 = c1 != RTC_EMPTY_CHILD && near[1] <= far[1] && far[1] >= tlo32 && near[1] <= lim;
-            if (h0 && h1) {
-                bool swap = near[1] < near[0];
-                int first = swap ? c1 : c0, second = swap ? c0 : c1;
-                stack[sp * kStride] = second; sp++;
-                node = first;
-                continue;
-            } else if (h0) { node = c0; continue; }
-            else if (h1) { node = c1; continue; }
+            if (!RTC_NODE_SPLIT) next = bvh2_visit<kStride>(r, sr, lim, stack, sp);
+            if (next != RTC_EMPTY_CHILD) { node = next; continue; }
         } else {
             int code = ~node;
             int first = code >> 4, count = (code & 15) + 1;
@@ -680,11 +748,22 @@ __device__ __forceinline__ bool traverse_bvh4(const DScene<R>& S, const Ray<R>& 
         if (node >= 0) {
             vis.cnt.work(W_NODE);
             vis.cnt.work(W_NODE4);
-            float b[24];
-            int c[4];
+#ifdef RTC_LANE_STATS_DETAIL   /* one-off measurement: csg_evals = four-wide visits by unordered walks, container_passes = wave-uniform four-wide visits */
+            if (V::kUnordered) vis.cnt.work(W_CSG);
+            if (__builtin_amdgcn_ballot_w64(node != __builtin_amdgcn_readfirstlane(node)) == 0ull) vis.cnt.work(W_CONTAINER);
+#endif
+            float lim = (float)vis.limit();
+            if (V::Cnt::kFar) lim -= base32;
+            lim += fabsf(lim) * 1e-6f;
+            if (V::Cnt::kFar) lim += lim_pad;
+            const SlabRay sr = {ix, iy, iz, ox, oy, oz, tlo32};
+            constexpr bool kAnyOrder = !RTC_BVH4_SORT_ANYHIT && V::kUnordered;
+            int next;
+            NodeRec4 r;
             const int node0 = __builtin_amdgcn_readfirstlane(node);
             if (__builtin_amdgcn_ballot_w64(node != node0) == 0ull) {
-                // every active lane at the same node: the record comes through the scalar unit (28 of its 32 dwords)
+                // every active lane at the same node: the record comes through the scalar unit (28 of its 32 dwords) and the
+                // visit's arithmetic reads it from scalar registers (a copy of bvh4_visit of its own)
                 typedef float f16v __attribute__((ext_vector_type(16)));
                 typedef float f8v __attribute__((ext_vector_type(8)));
                 typedef int i4v __attribute__((ext_vector_type(4)));
@@ -692,61 +771,19 @@ __device__ __forceinline__ bool traverse_bvh4(const DScene<R>& S, const Ray<R>& 
                 const BvhNode4* p0 = uniform_ptr(nodes + node0);
                 asm volatile("s_load_dwordx16 %0, %3, 0x0\n\ts_load_dwordx8 %1, %3, 0x40\n\ts_load_dwordx4 %2, %3, 0x60\n\ts_waitcnt lgkmcnt(0)"
                              : "=&s"(r0), "=&s"(r1), "=&s"(r2) : "s"(p0) : "memory");
-#pragma unroll
-                for (int k = 0; k < 16; k++) b[k] = r0[k];
-#pragma unroll
-                for (int k = 0; k < 8; k++) b[16 + k] = r1[k];
-                c[0] = r2[0]; c[1] = r2[1]; c[2] = r2[2]; c[3] = r2[3];
+                const NodeRec4 rs = {{r0[0], r0[1], r0[2], r0[3], r0[4], r0[5], r0[6], r0[7], r0[8], r0[9], r0[10], r0[11], r0[12], r0[13], r0[14], r0[15],
+                                      r1[0], r1[1], r1[2], r1[3], r1[4], r1[5], r1[6], r1[7]}, {r2[0], r2[1], r2[2], r2[3]}};
+                if (RTC_NODE_SPLIT) next = bvh4_visit<kStride, kAnyOrder>(rs, sr, lim, stack, sp); else r = rs;
             } else {
                 const float4* q = reinterpret_cast<const float4*>(nodes + node);
-#pragma unroll
-                for (int k = 0; k < 6; k++) { const float4 v = q[k]; b[4 * k] = v.x; b[4 * k + 1] = v.y; b[4 * k + 2] = v.z; b[4 * k + 3] = v.w; }
-                const float4 v = q[6];
-                c[0] = __float_as_int(v.x); c[1] = __float_as_int(v.y); c[2] = __float_as_int(v.z); c[3] = __float_as_int(v.w);
+                const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3], q4 = q[4], q5 = q[5], q6 = q[6];
+                const NodeRec4 rv = {{q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w,
+                                      q4.x, q4.y, q4.z, q4.w, q5.x, q5.y, q5.z, q5.w},
+                                     {__float_as_int(q6.x), __float_as_int(q6.y), __float_as_int(q6.z), __float_as_int(q6.w)}};
+                if (RTC_NODE_SPLIT) next = bvh4_visit<kStride, kAnyOrder>(rv, sr, lim, stack, sp); else r = rv;
             }
-            float lim = (float)vis.limit();
-            if (V::Cnt::kFar) lim -= base32;
-            lim += fabsf(lim) * 1e-6f;
-            if (V::Cnt::kFar) lim += lim_pad;
-            unsigned int key[4];
-            bool hit[4];
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const float* lo = b + 6 * k; const float* hi = lo + 3;
-                float x0 = fmaf(lo[0], ix, ox), x1 = fmaf(hi[0], ix, ox);
-                float y0 = fmaf(lo[1], iy, oy), y1 = fmaf(hi[1], iy, oy);
-                float z0 = fmaf(lo[2], iz, oz), z1 = fmaf(hi[2], iz, oz);
-                float n = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
-                float f = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
-                n -= fabsf(n) * 1e-5f;
-                f += fabsf(f) * 1e-5f;
-                hit[k] = c[k] != RTC_EMPTY_CHILD && n <= f && f >= tlo32 && n <= lim;
-                key[k] = hit[k] ? ((__float_as_uint(fmaxf(n, 0.0f)) & ~3u) | (unsigned)k) : 0xFFFFFFFFu;
-            }
-            if (!RTC_BVH4_SORT_ANYHIT && V::kUnordered) {
-                // any-hit queries and passes with a fixed far bound need no order among the children: one that is hit is entered, the others pushed
-                int next = RTC_EMPTY_CHILD;
-#pragma unroll
-                for (int k = 3; k >= 0; k--)
-                    if (hit[k]) {
-                        if (next != RTC_EMPTY_CHILD) { stack[sp * kStride] = next; sp++; }
-                        next = c[k];
-                    }
-                if (next != RTC_EMPTY_CHILD) { node = next; continue; }
-            } else {
-#define RTC_CE(i, j) { const unsigned int lo_ = key[i] < key[j] ? key[i] : key[j], hi_ = key[i] < key[j] ? key[j] : key[i]; key[i] = lo_; key[j] = hi_; }
-                RTC_CE(0, 1) RTC_CE(2, 3) RTC_CE(0, 2) RTC_CE(1, 3) RTC_CE(1, 2)
-#undef RTC_CE
-#define RTC_PICK(kk) (((kk) & 3u) == 0u ? c[0] : ((kk) & 3u) == 1u ? c[1] : ((kk) & 3u) == 2u ? c[2] : c[3])
-                if (key[0] != 0xFFFFFFFFu) {
-                    if (key[3] != 0xFFFFFFFFu) { stack[sp * kStride] = RTC_PICK(key[3]); sp++; }
-                    if (key[2] != 0xFFFFFFFFu) { stack[sp * kStride] = RTC_PICK(key[2]); sp++; }
-                    if (key[1] != 0xFFFFFFFFu) { stack[sp * kStride] = RTC_PICK(key[1]); sp++; }
-                    node = RTC_PICK(key[0]);
-                    continue;
-                }
-            }
-#undef RTC_PICK
+            if (!RTC_NODE_SPLIT) next = bvh4_visit<kStride, kAnyOrder>(r, sr, lim, stack, sp);
+            if (next != RTC_EMPTY_CHILD) { node = next; continue; }
         } else {
             int code = ~node;
             int first = code >> 4, count = (code & 15) + 1;

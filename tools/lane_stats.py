@@ -6,7 +6,7 @@ from ray_tracer_challenge_amd import _ffi
 from ray_tracer_challenge_amd.compile import compile_scene
 from ray_tracer_challenge_amd.scene_io import load_world
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-NAMES = ["bvh_node_visits", "triangle_tests", "analytic_leaf_tests", "csg_evals", "shaded_hits", "light_samples", "container_passes", "pattern_evals"]
+NAMES = ["bvh_node_visits", "triangle_tests", "analytic_leaf_tests", "csg_evals", "shaded_hits", "light_samples", "container_passes", "pattern_evals", "wide_node_visits"]
 prod = os.path.abspath(sys.argv[2]) if len(sys.argv) > 2 else _ffi.LIB_PATH
 res = {}
 for lib in (prod, os.path.abspath(sys.argv[1])):
@@ -18,7 +18,7 @@ for lib in (prod, os.path.abspath(sys.argv[1])):
         with _ffi.Scene(compile_scene(world)) as sc:
             st = {}
             sc.render(cam, precision="fp64", stats=st, count_work=True, feedback=False)
-            res[(lib == prod, name)] = st["work"]
+            res[(lib == prod, name)] = list(st["work"]) + [st.get("wide_node_visits", 0)]
 for name in ("dragons", "teapot", "cover"):
     lane, wave = res[(True, name)], res[(False, name)]
     print(name)
