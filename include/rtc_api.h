@@ -131,7 +131,13 @@ typedef struct {
     const double *light_geom;      /* [n][9] position | corner, per-step uvec, per-step vvec */
     const int32_t *light_steps;    /* [n][3] usteps, vsteps, jitter */
     const double *light_intensity; /* [n][3] */
+    /* How rtc_scene_create builds the triangle BVH.  0: binned SAH on the host -- the best tree, tens of milliseconds for 10^5
+     * triangles: for scenes that are rendered many times.  RTC_BUILD_ON_DEVICE: on the GPU from the uploaded rows (Morton
+     * order + parallel locally-ordered clustering, ~2 ms for 1.4 10^5 triangles; frames ~1.1 x the SAH tree's): for scenes
+     * rendered once, the reference's own use (main.py:305-354: one frame per scene). */
+    int32_t build_flags;
 } rtc_scene_desc;
+#define RTC_BUILD_ON_DEVICE 1
 
 /* Camera (renderer.py:667-692) with its transform already inverted (ray_for_pixel :747-748). */
 typedef struct {

@@ -543,6 +543,8 @@ const bool g_tune_waves = [] { const char* e = getenv("RTC_TUNE_WAVES"); return 
 float g_split_t = [] { const char* e = getenv("RTC_SPLIT_T"); return e ? (float)atof(e) : 0.0f; }();
 float g_split16 = [] { const char* e = getenv("RTC_SPLIT16"); return e ? (float)atof(e) : 0.35f; }();     // the same for a 2x2 part
 
+int rebuild_triangle_bvh_device(rtc_scene* sc, bool again = false);
+
 int create_impl(const rtc_scene_desc& d, rtc_scene* sc) {
     {
         hipDeviceProp_t prop;
@@ -567,6 +569,18 @@ int create_impl(const rtc_scene_desc& d, rtc_scene* sc) {
     int obj_leaf = obox.size() <= 4 ? 4 : 1;
     if (const char* e = getenv("RTC_OBJ_LEAF")) { int v = atoi(e); if (v >= 1 && v <= 16) obj_leaf = v; }
     rtc::Bvh bvh = rtc::build_bvh(obox, obj_leaf, RTC_BVH_STACK - 2);
+    // RTC_BUILD_ON_DEVICE: no triangle tree is built here; the rows go up and rebuild_triangle_bvh_device makes it (end of this function)
+    // (only for meshes the host build takes longer over than the GPU build's fixed costs -- some thirty allocations, fifty rounds of
+    // small kernels, ~10 ms the first time: teapot, 6 320 triangles, host 3.5 ms)
+    const bool device_build = (d.build_flags & RTC_BUILD_ON_DEVICE) != 0 && tprim.size() >= 16384;
+    double tri_max_abs = 0;
+    if (device_build) {
+        for (const rtc::Aabb& b : tbox)
+            for (int k = 0; k < 3; k++) tri_max_abs = std::max(tri_max_abs, std::max(std::fabs(b.lo[k]), std::fabs(b.hi[k])));
+        tbox.clear();
+    }
+    std::vector<int32_t> tprim_all;
+    if (device_build) tprim_all.swap(tprim);
     rtc::Bvh tbvh = rtc::build_bvh(tbox, tri_leaf, RTC_BVH_STACK - 2);
     if (bvh.depth > RTC_BVH_STACK - 1 || tbvh.depth > RTC_BVH_STACK - 1) return fail(RTC_ERR_LIMIT, "BVH depth exceeds traversal stack");
     sc->bvh_nodes = bvh.n_nodes() + tbvh.n_nodes(); sc->bvh_depth = std::max(bvh.depth, tbvh.depth);
@@ -615,8 +629,9 @@ int create_impl(const rtc_scene_desc& d, rtc_scene* sc) {
     }
     {
         const int32_t* items_dev = nullptr;
-        if (int rc_ = A.upload(tprim.data(), tprim.size(), &items_dev)) return rc_;
-        sc->d_titems = const_cast<int32_t*>(items_dev); sc->n_titems = (int)tprim.size(); sc->n_tris = d.n_tris;
+        const std::vector<int32_t>& titems = device_build ? tprim_all : tprim;
+        if (int rc_ = A.upload(titems.data(), titems.size(), &items_dev)) return rc_;
+        sc->d_titems = const_cast<int32_t*>(items_dev); sc->n_titems = (int)titems.size(); sc->n_tris = d.n_tris;
     }
     UP(unbounded_prims, d.unbounded_prim, d.n_unbounded);
     {
@@ -669,6 +684,7 @@ int create_impl(const rtc_scene_desc& d, rtc_scene* sc) {
         double max_abs = 0;
         for (const rtc::Bvh* b : {&bvh, &tbvh})
             for (double v : b->box) if (std::isfinite(v)) max_abs = std::max(max_abs, std::fabs(v));
+        if (std::isfinite(tri_max_abs)) max_abs = std::max(max_abs, tri_max_abs);
         sc->max_abs = max_abs;
         const double pad_abs = RTC_PAD_OF_EXTENT * max_abs;
         auto pack = [pad_abs](const rtc::Bvh& b) {
@@ -722,6 +738,7 @@ int create_impl(const rtc_scene_desc& d, rtc_scene* sc) {
         sc->light_cells += d.light_type[i] == 1 ? (long long)d.light_steps[3 * i] * d.light_steps[3 * i + 1] : 1;
         if (d.light_type[i] == 1 && d.light_steps[3 * i + 2]) sc->has_jitter = true;
     }
+    if (device_build) return rebuild_triangle_bvh_device(sc, false);
     return 0;
 }
 
@@ -752,10 +769,10 @@ int check_render_args(const rtc_scene* scene, const rtc_camera* cam, const rtc_r
 
 // The triangle BVH rebuilt on the GPU from the resident triangle rows (rtc_lbvh.hpp).  Builds into
 // fresh buffers and swaps them in only if the tree fits the traversal stack.
-int rebuild_triangle_bvh_device(rtc_scene* sc, bool again = false) {
+int rebuild_triangle_bvh_device(rtc_scene* sc, bool again) {
     const int n = sc->n_titems;
     if (n == 0) return 0;
-    const int n_leaves = (n + 1) / 2;
+    const int n_leaves = (n + RTC_GPU_LEAF - 1) / RTC_GPU_LEAF;
     DeviceArena fresh, temp;
     auto alloc = [](DeviceArena& A, size_t bytes, void** out) -> int {
         HIP_TRY(hipMalloc(out, bytes ? bytes : 1));
@@ -785,23 +802,72 @@ int rebuild_triangle_bvh_device(rtc_scene* sc, bool again = false) {
     hipLaunchKernelGGL(rtc::lbvh_boxes_kernel, grid_for(n), blk, 0, nullptr, n, sc->d_titems, sc->d64.tri_geom, (float*)p_boxes, (uint32_t*)p_bounds,
                        RTC_PAD_OF_EXTENT * sc->max_abs);
     int32_t deepest = 0;
-    // finest Morton grid first (21 bits per axis); a coarser one if that tree is too deep for the traversal stack
-    const int drop_bits[3] = {0, 18, 33};
-    for (int attempt = 0; attempt < 3; attempt++) {
+    // The topology: PLOC over the Morton order of the finest grid (21 bits per axis) first -- merges chosen by surface area,
+    // rtc_lbvh_device.hpp -- then, should that tree be too deep for the traversal stack or not finish, the Karras radix tree on
+    // the same grid, then on coarser ones.  (Development: RTC_GPU_BUILDER=lbvh skips PLOC, RTC_PLOC_RADIUS sets its search radius.)
+    struct Attempt { bool ploc; int drop_bits; };
+    const Attempt attempts[4] = {{true, 0}, {false, 0}, {false, 18}, {false, 33}};
+    static const bool use_ploc = [] { const char* e = getenv("RTC_GPU_BUILDER"); return !e || strcmp(e, "lbvh") != 0; }();
+    static const int ploc_radius = [] { const char* e = getenv("RTC_PLOC_RADIUS"); int v = e ? atoi(e) : 16; return v < 1 ? 1 : v > 256 ? 256 : v; }();
+    void *p_cl0 = nullptr, *p_cl1 = nullptr, *p_cbox = nullptr, *p_near = nullptr, *p_flags = nullptr, *p_offs = nullptr, *p_st = nullptr, *p_scan = nullptr;
+    size_t scan_bytes = 0;
+    int last_drop = -1;
+    for (int attempt = 0; attempt < 4; attempt++) {
+        const Attempt at = attempts[attempt];
+        if (at.ploc && (!use_ploc || n_leaves < 2)) continue;
         TRY_B(hipMemset(p_pin, 0xFF, n_nodes * sizeof(int32_t)));
         TRY_B(hipMemset(p_pleaf, 0xFF, (size_t)n_leaves * sizeof(int32_t)));
         TRY_B(hipMemset(p_arr, 0, n_nodes * sizeof(uint32_t)));
         TRY_B(hipMemset(p_deep, 0, sizeof(int32_t)));
-        hipLaunchKernelGGL(rtc::lbvh_keys_kernel, grid_for(n), blk, 0, nullptr, n, (const float*)p_boxes, (const uint32_t*)p_bounds, drop_bits[attempt],
-                           (uint64_t*)p_keys, (uint32_t*)p_idx);
-        size_t tmp_bytes = 0;
-        TRY_B(rocprim::radix_sort_pairs(nullptr, tmp_bytes, (uint64_t*)p_keys, (uint64_t*)p_sorted, (uint32_t*)p_idx, (uint32_t*)p_sidx, (size_t)n, 0, 64,
-                                        (hipStream_t) nullptr));
-        if (!p_tmp && (rc = alloc(temp, tmp_bytes, &p_tmp))) return bail(rc);
-        TRY_B(rocprim::radix_sort_pairs(p_tmp, tmp_bytes, (uint64_t*)p_keys, (uint64_t*)p_sorted, (uint32_t*)p_idx, (uint32_t*)p_sidx, (size_t)n, 0, 64,
-                                        (hipStream_t) nullptr));
+        if (at.drop_bits != last_drop) {
+            hipLaunchKernelGGL(rtc::lbvh_keys_kernel, grid_for(n), blk, 0, nullptr, n, (const float*)p_boxes, (const uint32_t*)p_bounds, at.drop_bits,
+                               (uint64_t*)p_keys, (uint32_t*)p_idx);
+            size_t tmp_bytes = 0;
+            TRY_B(rocprim::radix_sort_pairs(nullptr, tmp_bytes, (uint64_t*)p_keys, (uint64_t*)p_sorted, (uint32_t*)p_idx, (uint32_t*)p_sidx, (size_t)n, 0, 64,
+                                            (hipStream_t) nullptr));
+            if (!p_tmp && (rc = alloc(temp, tmp_bytes, &p_tmp))) return bail(rc);
+            TRY_B(rocprim::radix_sort_pairs(p_tmp, tmp_bytes, (uint64_t*)p_keys, (uint64_t*)p_sorted, (uint32_t*)p_idx, (uint32_t*)p_sidx, (size_t)n, 0, 64,
+                                            (hipStream_t) nullptr));
+            last_drop = at.drop_bits;
+        }
         if (n_leaves == 1) {
             hipLaunchKernelGGL(rtc::lbvh_single_kernel, dim3(1), dim3(64), 0, nullptr, n, (const uint32_t*)p_sidx, (const float*)p_boxes, (rtc::BvhNode*)p_nodes);
+        } else if (at.ploc) {
+            if (!p_cl0) {
+                TRY_B(rocprim::exclusive_scan(nullptr, scan_bytes, (unsigned long long*)nullptr, (unsigned long long*)nullptr, 0ull, (size_t)n_leaves,
+                                              rocprim::plus<unsigned long long>(), (hipStream_t) nullptr));
+                if ((rc = alloc(temp, (size_t)n_leaves * sizeof(int32_t), &p_cl0)) || (rc = alloc(temp, (size_t)n_leaves * sizeof(int32_t), &p_cl1)) ||
+                    (rc = alloc(temp, 6 * (2 * (size_t)n_leaves) * sizeof(float), &p_cbox)) || (rc = alloc(temp, (size_t)n_leaves * sizeof(int32_t), &p_near)) ||
+                    (rc = alloc(temp, (size_t)n_leaves * sizeof(unsigned long long), &p_flags)) || (rc = alloc(temp, (size_t)n_leaves * sizeof(unsigned long long), &p_offs)) ||
+                    (rc = alloc(temp, sizeof(rtc::PlocState), &p_st)) || (rc = alloc(temp, scan_bytes ? scan_bytes : 1, &p_scan)))
+                    return bail(rc);
+            }
+            hipLaunchKernelGGL(rtc::ploc_init_kernel, grid_for(n_leaves), blk, 0, nullptr, n_leaves, n, (const uint32_t*)p_sidx, (const float*)p_boxes, (int32_t*)p_cl0,
+                               (float*)p_cbox, (rtc::PlocState*)p_st);
+            rtc::PlocState st = {n_leaves, 0, 0, 0};
+            void* cl[2] = {p_cl0, p_cl1};
+            int cur = 0;
+            // batches of iterations between looks at the count (every look is a wait); a mesh takes ~ 2 log2(leaves) iterations
+            for (int batch = 0; batch < 64 && st.n > 1; batch++) {
+                for (int it = 0; it < 16; it++) {
+                    hipLaunchKernelGGL(rtc::ploc_nearest_kernel, grid_for(n_leaves), blk, 0, nullptr, (const rtc::PlocState*)p_st, ploc_radius, (const int32_t*)cl[cur],
+                                       (const float*)p_cbox, (int32_t*)p_near);
+                    hipLaunchKernelGGL(rtc::ploc_flags_kernel, grid_for(n_leaves), blk, 0, nullptr, (const rtc::PlocState*)p_st, n_leaves, (const int32_t*)p_near,
+                                       (unsigned long long*)p_flags);
+                    TRY_B(rocprim::exclusive_scan(p_scan, scan_bytes, (unsigned long long*)p_flags, (unsigned long long*)p_offs, 0ull, (size_t)n_leaves,
+                                                  rocprim::plus<unsigned long long>(), (hipStream_t) nullptr));
+                    hipLaunchKernelGGL(rtc::ploc_merge_kernel, grid_for(n_leaves), blk, 0, nullptr, (rtc::PlocState*)p_st, n_leaves, n, (const int32_t*)p_near,
+                                       (const unsigned long long*)p_flags, (const unsigned long long*)p_offs, (const int32_t*)cl[cur], (int32_t*)cl[1 - cur],
+                                       (float*)p_cbox, (rtc::BvhNode*)p_nodes, (int32_t*)p_pin, (int32_t*)p_pleaf);
+                    hipLaunchKernelGGL(rtc::ploc_advance_kernel, dim3(1), dim3(1), 0, nullptr, (rtc::PlocState*)p_st, n_leaves, (const unsigned long long*)p_flags,
+                                       (const unsigned long long*)p_offs);
+                    cur = 1 - cur;
+                }
+                TRY_B(hipMemcpy(&st, p_st, sizeof(st), hipMemcpyDeviceToHost));
+            }
+            if (getenv("RTC_BVH_INFO")) fprintf(stderr, "[rtc] PLOC: %d leaves, radius %d, %d iterations, %d merges, %d clusters left\n", n_leaves, ploc_radius, st.iterations, st.merges, st.n);
+            if (st.n != 1 || st.merges != n_leaves - 1) continue;            // did not finish: the radix tree instead
+            hipLaunchKernelGGL(rtc::lbvh_depth_kernel, grid_for(n_leaves), blk, 0, nullptr, n_leaves, (const int32_t*)p_pin, (const int32_t*)p_pleaf, (int32_t*)p_deep);
         } else {
             hipLaunchKernelGGL(rtc::lbvh_leaf_keys_kernel, grid_for(n_leaves), blk, 0, nullptr, n_leaves, (const uint64_t*)p_sorted, (uint64_t*)p_lkeys);
             hipLaunchKernelGGL(rtc::lbvh_inner_kernel, grid_for(n_leaves - 1), blk, 0, nullptr, n_leaves, n, (const uint64_t*)p_lkeys, (rtc::BvhNode*)p_nodes,
@@ -812,6 +878,7 @@ int rebuild_triangle_bvh_device(rtc_scene* sc, bool again = false) {
         }
         TRY_B(hipGetLastError());
         TRY_B(hipMemcpy(&deepest, p_deep, sizeof(deepest), hipMemcpyDeviceToHost));      // also waits for the build
+        if (getenv("RTC_BVH_INFO")) fprintf(stderr, "[rtc] GPU build attempt %d (%s, grid - %d bits): depth %d\n", attempt, at.ploc ? "PLOC" : "radix tree", at.drop_bits, deepest);
         if (n_leaves == 1 || deepest <= RTC_BVH_STACK - 1) break;
     }
     // the four-wide form rays walk, collapsed from the binary tree on the device (heights first: what fits the traversal stack)
@@ -840,7 +907,7 @@ int rebuild_triangle_bvh_device(rtc_scene* sc, bool again = false) {
     sc->d_tb_row = (int32_t*)p_row; sc->d_tparent = (int32_t*)p_pin; sc->d_tarrived = (uint32_t*)p_arr2;
     sc->bvh_nodes = sc->d64.n_bvh_nodes + (int)n_nodes;
     sc->bvh_depth = std::max(sc->obj_depth, (int)deepest);
-    sc->bvh_max_leaf = std::max(sc->obj_max_leaf, std::min(n, 2));
+    sc->bvh_max_leaf = std::max(sc->obj_max_leaf, std::min(n, RTC_GPU_LEAF));
     bool grew = false;
     if (int rc2 = refresh_triangle_root_box(sc, &grew)) return rc2;
     if (grew && !again) return rebuild_triangle_bvh_device(sc, true);

@@ -5,6 +5,14 @@
 #include "rtc_device.hpp"
 #include "rtc_lbvh.hpp"
 
+#ifndef RTC_GPU_LEAF
+// Triangles per leaf of a GPU-built tree = consecutive rows of the Morton order.  ONE: with two, which triangles share a leaf is
+// decided by the Morton order alone, and that pairing -- not the tree above it -- was most of what the GPU-built trees lost to
+// the host's SAH tree (dragons 1080p fp64, frame on the GPU tree / frame on the host tree: radix tree 1.57 -> 1.18, PLOC 1.35 ->
+// 1.12; teapot 1.42 -> 1.06, 1.30 -> 1.03; profiles/r03_experiments/gpu_tree_builders.txt).  Costs twice the nodes.
+#define RTC_GPU_LEAF 1
+#endif
+
 namespace rtc {
 
 // floats <-> unsigned ints with the same order (for atomicMin / atomicMax)
@@ -49,11 +57,11 @@ __global__ void lbvh_keys_kernel(int n, const float* boxes, const uint32_t* boun
 // leaf j = sorted items 2j and 2j + 1; its key is the first one's
 __global__ void lbvh_leaf_keys_kernel(int n_leaves, const uint64_t* sorted, uint64_t* leaf_keys) {
     int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j < n_leaves) leaf_keys[j] = sorted[2 * (size_t)j];
+    if (j < n_leaves) leaf_keys[j] = sorted[RTC_GPU_LEAF * (size_t)j];
 }
 
 __device__ __forceinline__ int32_t lbvh_leaf_code(int j, int n_items) {
-    int first = 2 * j, count = n_items - first < 2 ? n_items - first : 2;
+    int first = RTC_GPU_LEAF * j, count = n_items - first < RTC_GPU_LEAF ? n_items - first : RTC_GPU_LEAF;
     return ~((first << 4) | (count - 1));
 }
 
@@ -79,7 +87,7 @@ __global__ void lbvh_refit_kernel(int n_leaves, int n_items, const uint32_t* sor
     int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n_leaves) return;
     float b[6] = {3.0e38f, 3.0e38f, 3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};
-    for (int q = 2 * j; q < 2 * j + 2 && q < n_items; q++) {
+    for (int q = RTC_GPU_LEAF * j; q < RTC_GPU_LEAF * j + RTC_GPU_LEAF && q < n_items; q++) {
         const float* t = boxes + 6 * (size_t)sorted[q];
         for (int a = 0; a < 3; a++) { b[a] = fminf(b[a], t[a]); b[3 + a] = fmaxf(b[3 + a], t[3 + a]); }
     }
@@ -99,11 +107,103 @@ __global__ void lbvh_refit_kernel(int n_leaves, int n_items, const uint32_t* sor
     }
 }
 
+// ---- PLOC: the topology of the binary tree by parallel locally-ordered clustering (Meister & Bittner 2017) ----
+// The Karras radix tree above splits wherever the Morton codes' bits say; its boxes overlap where a mesh crosses a cell
+// boundary, and rays pay for that (frame 1.65 x the host SAH tree's on the dragons).  PLOC builds bottom-up instead: the
+// clusters -- at first the leaves, in Morton order -- each look for the neighbour within `radius` places whose union with
+// them has the smallest surface area; two clusters that choose each other merge into a node; the survivors are compacted
+// in order; repeat until one cluster is left.  Local in memory like the LBVH, but every merge is chosen by area.
+// Cluster ids: < n_leaves = leaf j (sorted items 2j, 2j + 1), else inner node id - n_leaves.  Inner nodes are numbered from
+// the back (the k-th merge of the whole build gets node n_leaves - 2 - k), so that the last merge, the root, is node 0 as
+// the walks and the kernels below expect.  Boxes of clusters: cbox[cid][6].
+struct PlocState { int32_t n; int32_t merges; int32_t iterations; int32_t pad; };      // clusters left, merges done so far
+
+__device__ __forceinline__ float ploc_area(const float* a, const float* b) {
+    const float dx = fmaxf(a[3], b[3]) - fminf(a[0], b[0]), dy = fmaxf(a[4], b[4]) - fminf(a[1], b[1]), dz = fmaxf(a[5], b[5]) - fminf(a[2], b[2]);
+    return dx * dy + dy * dz + dz * dx;
+}
+__global__ void ploc_init_kernel(int n_leaves, int n_items, const uint32_t* sorted, const float* boxes, int32_t* cluster, float* cbox, PlocState* st) {
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j == 0) { st->n = n_leaves; st->merges = 0; st->iterations = 0; st->pad = 0; }
+    if (j >= n_leaves) return;
+    float b[6] = {3.0e38f, 3.0e38f, 3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};
+    for (int q = RTC_GPU_LEAF * j; q < RTC_GPU_LEAF * j + RTC_GPU_LEAF && q < n_items; q++) {
+        const float* t = boxes + 6 * (size_t)sorted[q];
+        for (int a = 0; a < 3; a++) { b[a] = fminf(b[a], t[a]); b[3 + a] = fmaxf(b[3 + a], t[3 + a]); }
+    }
+    for (int a = 0; a < 6; a++) cbox[6 * (size_t)j + a] = b[a];
+    cluster[j] = j;
+}
+// nearest neighbour of every cluster within `radius` places (smallest area of the union; ties to the lower place, so that
+// "i and j choose each other" is well defined)
+__global__ void ploc_nearest_kernel(const PlocState* st, int radius, const int32_t* cluster, const float* cbox, int32_t* nearest) {
+    const int n = st->n;
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n <= 1 || i >= n) return;
+    float mine[6];
+    for (int a = 0; a < 6; a++) mine[a] = cbox[6 * (size_t)cluster[i] + a];
+    float best = 3.0e38f; int at = -1;
+    const int lo = i - radius < 0 ? 0 : i - radius, hi = i + radius >= n ? n - 1 : i + radius;
+    for (int j = lo; j <= hi; j++) {
+        if (j == i) continue;
+        const float area = ploc_area(mine, cbox + 6 * (size_t)cluster[j]);
+        if (area < best) { best = area; at = j; }
+    }
+    nearest[i] = at;
+}
+// per place: low word 1 if the cluster survives at its place (merged pairs survive at the lower place), high word 1 if a
+// node is made there; scanned by the caller (exclusive, 64-bit adds = both counts at once)
+__global__ void ploc_flags_kernel(const PlocState* st, int n_max, const int32_t* nearest, unsigned long long* flags) {
+    const int n = st->n;
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_max) return;
+    unsigned long long f = 0ull;
+    if (n > 1 && i < n) {
+        const int j = nearest[i];
+        const bool mutual = j >= 0 && nearest[j] == i;
+        if (!mutual) f = 1ull;
+        else if (i < j) f = 1ull | (1ull << 32);
+    }
+    flags[i] = f;
+}
+__global__ void ploc_merge_kernel(PlocState* st, int n_leaves, int n_items, const int32_t* nearest, const unsigned long long* flags, const unsigned long long* offsets,
+                                  const int32_t* cluster, int32_t* cluster_out, float* cbox, BvhNode* nodes, int32_t* parent_inner, int32_t* parent_leaf) {
+    const int n = st->n;
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n <= 1 || i >= n) return;
+    const unsigned long long f = flags[i], off = offsets[i];
+    if (!(f & 1ull)) return;                                             // the upper half of a merged pair: its partner carries it
+    const int pos = (int)(uint32_t)off;
+    if (!(f >> 32)) { cluster_out[pos] = cluster[i]; return; }
+    const int node = n_leaves - 2 - (st->merges + (int)(off >> 32));
+    const int32_t c[2] = {cluster[i], cluster[nearest[i]]};
+    float b[6];
+    for (int s = 0; s < 2; s++) {
+        const float* cb = cbox + 6 * (size_t)c[s];
+        for (int a = 0; a < 6; a++) nodes[node].box[6 * s + a] = cb[a];
+        for (int a = 0; a < 3; a++) { b[a] = s ? fminf(b[a], cb[a]) : cb[a]; b[3 + a] = s ? fmaxf(b[3 + a], cb[3 + a]) : cb[3 + a]; }
+        if (c[s] < n_leaves) { nodes[node].child[s] = lbvh_leaf_code(c[s], n_items); parent_leaf[c[s]] = (node << 1) | s; }
+        else { nodes[node].child[s] = c[s] - n_leaves; parent_inner[c[s] - n_leaves] = (node << 1) | s; }
+    }
+    nodes[node].pad[0] = nodes[node].pad[1] = 0;
+    for (int a = 0; a < 6; a++) cbox[6 * (size_t)(n_leaves + node) + a] = b[a];
+    cluster_out[pos] = n_leaves + node;
+    if (node == 0) parent_inner[0] = -1;
+}
+// after the merges of an iteration: the counts move on (one thread; the scan's last element + its flag = the totals)
+__global__ void ploc_advance_kernel(PlocState* st, int n_max, const unsigned long long* flags, const unsigned long long* offsets) {
+    if (blockIdx.x != 0 || threadIdx.x != 0 || st->n <= 1) return;
+    const unsigned long long total = offsets[n_max - 1] + flags[n_max - 1];
+    st->n = (int)(uint32_t)total;
+    st->merges += (int)(total >> 32);
+    st->iterations += 1;
+}
+
 // a single leaf (1 or 2 triangles): node 0 with one child
 __global__ void lbvh_single_kernel(int n_items, const uint32_t* sorted, const float* boxes, BvhNode* nodes) {
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
     float b[6] = {3.0e38f, 3.0e38f, 3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};
-    for (int q = 0; q < n_items && q < 2; q++) {
+    for (int q = 0; q < n_items && q < RTC_GPU_LEAF; q++) {
         const float* t = boxes + 6 * (size_t)sorted[q];
         for (int a = 0; a < 3; a++) { b[a] = fminf(b[a], t[a]); b[3 + a] = fmaxf(b[3 + a], t[3 + a]); }
     }

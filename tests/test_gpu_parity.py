@@ -486,6 +486,33 @@ def test_triangle_bvh_built_on_the_gpu(name, size, stride, oracle_cls):
             _against_oracle("gpu-built tree refitted in place: %s %dx%d" % (name, cam.hsize, cam.vsize), sample, cam, e, ie)
 
 
+@pytest.mark.parametrize("name,size,stride", [("dragons", (480, 192), 4), ("teapot", None, 3)])
+def test_scene_created_with_build_on_device(name, size, stride, oracle_cls):
+    """rtc_scene_desc::build_flags = RTC_BUILD_ON_DEVICE (what render() / render_multi() create their one-frame scenes with):
+    no host SAH build for meshes of 16 384 triangles and more, the tree comes from the GPU builder -- held to the ORACLE like
+    every other tree, and a refit and a rebuild on such a handle work like on any other."""
+    cam, world, _ = load_pack(name)
+    if size:
+        cam = cam.resized(*size)
+    sample = _oracle_sample(_ORACLE_SAMPLES, oracle_cls, (name, cam.hsize, cam.vsize, stride), world, cam, stride)
+    cs = compile_scene(world)
+    with _ffi.Scene(cs, device=0, build_on_device=True) as sc:
+        info = sc.info()
+        assert info["bvh_nodes"] > 0 and info["bvh_depth"] <= 31
+        if cs.counts["n_tris"] >= 16384:
+            assert info["bvh_max_leaf"] == 1                      # the GPU builder's trees (the host's hold two triangles a leaf)
+        a, ia = sc.render(cam, precision="fp64", want_ids=True)
+        a32, _ = sc.render(cam, precision="fp32")
+        _against_oracle("scene created with RTC_BUILD_ON_DEVICE: %s %dx%d" % (name, cam.hsize, cam.vsize), sample, cam, a, ia)
+        assert frac_off_by_more_than_one(a32[sample[1], sample[2]], sample[3]) <= 0.001
+        sc.update_triangles(cs.arrays["tri_geom"], cs.arrays["tri_norm"], refit=True)
+        b, ib = sc.render(cam, precision="fp64", want_ids=True)
+        _against_oracle("... refitted: %s" % name, sample, cam, b, ib)
+        sc.build_bvh_on_device()
+        c, ic = sc.render(cam, precision="fp64", want_ids=True)
+        _against_oracle("... rebuilt: %s" % name, sample, cam, c, ic)
+
+
 def _moved_teapot(fn):
     """The teapot pack with every triangle vertex moved by `fn` (object space): the world (for the oracle) and its
     compiled form (whose tri_geom / tri_norm rows are what rtc_scene_update_triangles takes)."""

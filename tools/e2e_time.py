@@ -18,6 +18,10 @@ def clock(f, n=1):
     return (time.perf_counter() - t0) / n * 1e3, r
 t_compile, cs = clock(lambda: compile_scene(world))
 _ffi.Scene(cs).close()
+t_create_dev, sc = clock(lambda: _ffi.Scene(cs, build_on_device=True))
+sc.render(cam, precision="fp64")
+t_first_dev, _ = clock(lambda: sc.render(cam, precision="fp64", feedback=False), 5)
+sc.close()
 t_create, sc = clock(lambda: _ffi.Scene(cs))
 st = {}
 sc.render(cam, precision="fp64", stats=st)
@@ -27,5 +31,6 @@ t_ppm, _ = clock(lambda: sc.render_ppm(cam, precision="fp64"), 5)
 sc.close()
 t_api, _ = clock(lambda: renderer.render_multi(cam, world))
 t_api2, _ = clock(lambda: renderer.render_multi(cam, world))
+print("%s %dx%d: rtc_scene_create with RTC_BUILD_ON_DEVICE %.1f ms, frame in plain order on that tree %.2f ms" % (name, w, h, t_create_dev, t_first_dev))
 print("%s %dx%d: compile_scene %.1f ms | rtc_scene_create %.1f ms | rtc_render (host buffers) %.2f ms of which kernel %.2f ms | with hit ids %.2f ms | rtc_render_ppm %.2f ms | render_multi(cam, world) %.1f ms, again %.1f ms"
       % (name, w, h, t_compile, t_create, t_render, st["kernel_ms"], t_ids, t_ppm, t_api, t_api2))
