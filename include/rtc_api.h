@@ -37,7 +37,7 @@ typedef enum {
 
 /* primitive kinds (shapes.py class -> code) */
 enum { RTC_SPHERE = 0, RTC_PLANE = 1, RTC_CUBE = 2, RTC_CYLINDER = 3, RTC_CONE = 4,
-       RTC_TRIANGLE = 5, RTC_CSG_ROOT = 8 };
+       RTC_TRIANGLE = 5, RTC_CSG_ROOT = 8, RTC_INSTANCE = 9 };
 /* CSG operations (shapes.py:409-422) */
 enum { RTC_CSG_UNION = 0, RTC_CSG_INTERSECT = 1, RTC_CSG_DIFFERENCE = 2 };
 /* pattern node types (shapes.py:1501-2033) */
@@ -60,7 +60,7 @@ enum { RTC_OP_EVAL = 0, RTC_OP_EVAL_AB = 1, RTC_OP_BLEND = 2, RTC_OP_PERTURB = 3
 /* A "prim code" names something a ray can be tested against:
  *   bits 31..28 kind, bit 27 = does NOT cast shadows, bits 26..0 index
  * index = leaf id for the analytic kinds, triangle-table row for RTC_TRIANGLE,
- * CSG-root row for RTC_CSG_ROOT. */
+ * CSG-root row for RTC_CSG_ROOT, row of `inst` for RTC_INSTANCE. */
 #define RTC_PRIM(kind, noshadow, index) \
     ((int32_t)(((uint32_t)(kind) << 28) | ((uint32_t)((noshadow) ? 1u : 0u) << 27) | ((uint32_t)(index) & 0x07FFFFFFu)))
 
@@ -131,6 +131,19 @@ typedef struct {
     const double *light_geom;      /* [n][9] position | corner, per-step uvec, per-step vvec */
     const int32_t *light_steps;    /* [n][3] usteps, vsteps, jitter */
     const double *light_intensity; /* [n][3] */
+    /* Instanced meshes (the reference loads dragon.obj six times for bounding_boxes.yml:59 ff.: one group of triangles under six
+     * transforms).  A mesh is stored ONCE, in the object space its vertices are given in -- where the reference itself runs
+     * Moller-Trumbore, shapes.py:812-830, det epsilon = EPSILON as there -- with one tree of its own; an instance is a prim of kind
+     * RTC_INSTANCE among the items: the ray is taken to object space by the instance's collapsed transform and walks the mesh's
+     * tree.  The leaves of an instance are numbered first_leaf .. first_leaf + count - 1 in row order, their per-leaf entries
+     * (leaf_kind = RTC_TRIANGLE, leaf_xform, leaf_material) are filled as for any triangle and leaf_tri = -2 - (mesh row). */
+    int32_t n_mesh_tris;
+    const double *mesh_geom;       /* [n_mesh_tris][12] object space: p1, e1, e2, EPSILON, 0, 0 */
+    const double *mesh_norm;       /* [n_mesh_tris][12] object space n1, n2, n3 (flat triangles repeat their face normal) */
+    int32_t n_meshes;
+    const int32_t *mesh_range;     /* [n_meshes][2] first row, rows */
+    int32_t n_instances;           /* at most RTC_MAX_INSTANCES */
+    const int32_t *inst;           /* [n_instances][4] mesh, xform row (world -> the mesh's object space), first leaf, material */
     /* How rtc_scene_create builds the triangle BVH.  0: binned SAH on the host -- the best tree, tens of milliseconds for 10^5
      * triangles: for scenes that are rendered many times.  RTC_BUILD_ON_DEVICE: on the GPU from the uploaded rows (Morton
      * order + parallel locally-ordered clustering, ~2 ms for 1.4 10^5 triangles; frames ~1.1 x the SAH tree's): for scenes
@@ -138,6 +151,7 @@ typedef struct {
     int32_t build_flags;
 } rtc_scene_desc;
 #define RTC_BUILD_ON_DEVICE 1
+#define RTC_MAX_INSTANCES 8        /* a ray keeps the instances whose boxes it enters in one 64-bit word, a byte each */
 
 /* Camera (renderer.py:667-692) with its transform already inverted (ray_for_pixel :747-748). */
 typedef struct {

@@ -29,12 +29,13 @@ _DESC_FIELDS = [
     ("n_textures", "n"), ("tex_off", "p"), ("tex_w", "p"), ("tex_h", "p"), ("tex_scale", "p"),
     ("tex_bytes", "n64"), ("tex_data", "p"),
     ("n_lights", "n"), ("light_type", "p"), ("light_geom", "p"), ("light_steps", "p"), ("light_intensity", "p"),
+    ("n_mesh_tris", "n"), ("mesh_geom", "p"), ("mesh_norm", "p"), ("n_meshes", "n"), ("mesh_range", "p"), ("n_instances", "n"), ("inst", "p"),
     ("build_flags", "flag"),
 ]
 BUILD_ON_DEVICE = 1
 _DTYPES = {"tex_off": np.int64, "tex_data": np.uint8}
 _F64 = {"leaf_minmax", "xform", "tri_geom", "tri_norm", "item_lo", "item_hi", "csg_bbox", "mat", "pat_inv", "pat_ab",
-        "pat_param", "pat_colors", "tex_scale", "light_geom", "light_intensity"}
+        "pat_param", "pat_colors", "tex_scale", "light_geom", "light_intensity", "mesh_geom", "mesh_norm"}
 
 
 class SceneDesc(C.Structure):

@@ -16,13 +16,26 @@ What it does, once per scene, on the host:
     them); planes and other unbounded things go to a list tested for every ray;
   * records every top-most CSG as a post-ordered list of nodes with contiguous leaf ranges,
     each node with its reference `bounds()` box (:391-396) and world->csg-local matrix;
-  * turns each material's pattern tree into a postfix program over pattern nodes.
+  * turns each material's pattern tree into a postfix program over pattern nodes;
+  * keeps a mesh the loader made more than once (the same block of vertex data under several
+    transforms: bounding_boxes.yml loads dragon.obj six times) ONCE, in its object space, with an
+    instance per use (rtc_scene_desc::inst) instead of flattening every copy to world space.
 """
+import hashlib
+import os
+
 import numpy as np
 
 EPSILON = 0.000001
 
-K_SPHERE, K_PLANE, K_CUBE, K_CYLINDER, K_CONE, K_TRIANGLE, K_CSG_ROOT = 0, 1, 2, 3, 4, 5, 8
+K_SPHERE, K_PLANE, K_CUBE, K_CYLINDER, K_CONE, K_TRIANGLE, K_CSG_ROOT, K_INSTANCE = 0, 1, 2, 3, 4, 5, 8, 9
+MAX_INSTANCES = 8            # RTC_MAX_INSTANCES (include/rtc_api.h)
+MIN_INSTANCE_TRIS = 1024     # smaller repeated meshes are flattened like everything else
+# instancing="auto": repeated meshes are instanced when that keeps at least this many triangles off the GPU (~ 290 bytes each in
+# the flattened form: rows in both precisions, normals, nodes, per-leaf entries).  Below it the flattened form is kept because it
+# is the faster one in fp64 (dragons 1080p: 0.43 flattened, 0.47 ms instanced -- the object-space ray beside the world-space one
+# costs the fp64 kernel registers it does not have; fp32: 0.415 -> 0.394 ms), DESIGN.md.
+AUTO_INSTANCE_SAVED_TRIS = 250000
 _KIND = {"Sphere": K_SPHERE, "Plane": K_PLANE, "Cube": K_CUBE, "Cylinder": K_CYLINDER, "Cone": K_CONE,
          "Triangle": K_TRIANGLE, "SmoothTriangle": K_TRIANGLE}
 _CSG_OP = {"CSGUnion": 0, "CSGIntersect": 1, "CSGDifference": 2}
@@ -59,7 +72,9 @@ class CompiledScene(object):
 
 
 class _Compiler(object):
-    def __init__(self):
+    def __init__(self, instancing="auto"):
+        env = os.environ.get("RTC_INSTANCING")               # development: 1 / 0 overrides the caller's choice
+        self.instancing = (env == "1") if env in ("0", "1") else instancing
         self.leaf_kind, self.leaf_xform, self.leaf_material, self.leaf_tri = [], [], [], []
         self.leaf_minmax, self.leaf_closed, self.leaf_objects = [], [], []
         self.leaf_lo = []                            # (leaf, lo, hi): world AABB of the analytic leaves that have a finite one
@@ -312,6 +327,38 @@ class _Compiler(object):
         xf = np.array(self.xforms, f64).reshape(-1, 4, 4) if self.xforms else np.zeros((0, 4, 4))
         mat_shadow = np.array([m[1] for m in self.materials] or [1], i32)
 
+        # ---- repeated meshes: which loader-made runs become instances of one object-space mesh ----
+        mesh_of_run, meshes = {}, []                       # run index -> (mesh, instance); meshes: (first mesh row, block)
+        if self.instancing and not self.csg_roots and not any(op == OP_PERTURB for op, _ in self.instr):    # (those scenes' kernels carry no instance walk)
+            groups = {}
+            for ri, (leaf0, n, xrow, mat, tri0, block, in_csg) in enumerate(self.runs):
+                if not in_csg and n >= MIN_INSTANCE_TRIS:
+                    groups.setdefault((n, hashlib.sha1(np.ascontiguousarray(block).tobytes()).digest()), []).append(ri)
+            n_inst, row0 = 0, 0
+            picked = sorted(groups.items(), key=lambda kv: -kv[0][0] * len(kv[1]))                  # the most triangles saved first
+            if self.instancing == "auto" and sum(k[0] * (min(len(m), MAX_INSTANCES) - 1) for k, m in picked if len(m) >= 2) < AUTO_INSTANCE_SAVED_TRIS:
+                picked = []
+            for key, members in picked:
+                members = members[:MAX_INSTANCES - n_inst]
+                if len(members) < 2:
+                    continue
+                for ri in members:
+                    mesh_of_run[ri] = (len(meshes), n_inst)
+                    n_inst += 1
+                meshes.append((row0, self.runs[members[0]][5]))
+                row0 += key[0]
+        if mesh_of_run:
+            # their triangles leave the world-space triangle table: the rows after them move up
+            gone = np.zeros(n_tris + 1, np.int64)
+            for ri in mesh_of_run:
+                _, n, _, _, tri0, _, _ = self.runs[ri]
+                gone[tri0:tri0 + n] = 1
+            new_row = np.arange(n_tris + 1) - np.concatenate([[0], np.cumsum(gone)[:-1]])
+            self.tri_single = [int(new_row[t]) for t in self.tri_single]
+            self.leaf_tri = [int(new_row[t]) if t >= 0 else t for t in self.leaf_tri]
+            self.runs = [(l0, n, x, m, int(new_row[t0]), b, c) for (l0, n, x, m, t0, b, c) in self.runs]
+            n_tris -= int(gone.sum())
+
         # per-leaf and per-triangle tables: the leaves that were walked one by one (the lists) and the loader-made runs (slices)
         ls, ts = np.array(self.leaf_single, np.int64), np.array(self.tri_single, np.int64)
 
@@ -326,8 +373,18 @@ class _Compiler(object):
         txf, tri_leaf, flat = table(n_tris, i32, ts, self.tri_xform), table(n_tris, i32, ts, self.tri_leaf), table(n_tris, bool, ts, self.tri_flat)
         rows = np.zeros((n_tris, 18))
         run_items = []
-        for leaf0, n, xrow, mat, tri0, block, in_csg in self.runs:
+        inst_rows, inst_prim, inst_lo, inst_hi = [None] * len(mesh_of_run), [None] * len(mesh_of_run), [None] * len(mesh_of_run), [None] * len(mesh_of_run)
+        for ri, (leaf0, n, xrow, mat, tri0, block, in_csg) in enumerate(self.runs):
             leaf_kind[leaf0:leaf0 + n], leaf_xform[leaf0:leaf0 + n], leaf_material[leaf0:leaf0 + n] = K_TRIANGLE, xrow, mat
+            if ri in mesh_of_run:
+                mesh, q = mesh_of_run[ri]
+                leaf_tri[leaf0:leaf0 + n] = -2 - (meshes[mesh][0] + np.arange(n))
+                a = np.linalg.inv(xf[xrow])                 # object -> world: the instance's box, from its own vertices
+                pts = block[:, :9].reshape(-1, 3) @ a[:3, :3].T + a[:3, 3]
+                inst_rows[q] = [mesh, xrow, leaf0, mat]
+                inst_prim[q] = prim_code(K_INSTANCE, mat_shadow[mat] == 0, q)
+                inst_lo[q], inst_hi[q] = pts.min(axis=0), pts.max(axis=0)
+                continue
             leaf_tri[leaf0:leaf0 + n] = np.arange(tri0, tri0 + n)
             txf[tri0:tri0 + n], tri_leaf[tri0:tri0 + n] = xrow, np.arange(leaf0, leaf0 + n)
             rows[tri0:tri0 + n] = block
@@ -404,6 +461,7 @@ class _Compiler(object):
                 root_prim.append(prim_code(K_CSG_ROOT, False, root))
                 root_lo.append(np.min(los, axis=0))
                 root_hi.append(np.max(his, axis=0))
+        root_prim, root_lo, root_hi = root_prim + inst_prim, root_lo + inst_lo, root_hi + inst_hi
         if root_prim:
             item_prim = np.concatenate([item_prim, np.array(root_prim, i32)])
             item_lo = np.concatenate([item_lo, np.array(root_lo, f64).reshape(-1, 3)])
@@ -425,6 +483,15 @@ class _Compiler(object):
         A["tri_geom"] = np.ascontiguousarray(tri_geom)
         A["tri_norm"] = np.ascontiguousarray(tri_norm)
         A["tri_leaf"] = arr(tri_leaf, i32, (-1,))
+        n_mesh_tris = sum(len(b) for _, b in meshes)
+        mesh_geom, mesh_norm = np.zeros((max(n_mesh_tris, 1), 12)), np.zeros((max(n_mesh_tris, 1), 12))
+        for r0, b in meshes:                               # object space, as the reference's own triangles hold it (shapes.py:799-811, 846-858)
+            g = mesh_geom[r0:r0 + len(b)]
+            g[:, 0:3], g[:, 3:6], g[:, 6:9], g[:, 9] = b[:, 0:3], b[:, 3:6] - b[:, 0:3], b[:, 6:9] - b[:, 0:3], EPSILON
+            mesh_norm[r0:r0 + len(b), 0:9] = b[:, 9:18]
+        A["mesh_geom"], A["mesh_norm"] = np.ascontiguousarray(mesh_geom), np.ascontiguousarray(mesh_norm)
+        A["mesh_range"] = arr([[r0, len(b)] for r0, b in meshes], i32, (-1, 2))
+        A["inst"] = arr(inst_rows, i32, (-1, 4))
         A["item_prim"] = arr(item_prim, i32, (-1,))
         A["item_lo"] = arr(item_lo, f64, (-1, 3))
         A["item_hi"] = arr(item_hi, f64, (-1, 3))
@@ -473,14 +540,18 @@ class _Compiler(object):
         C.update(n_leaves=n_leaves, n_xforms=len(self.xforms), n_tris=n_tris, n_items=int(len(item_prim)),
                  n_unbounded=len(unb), n_csg_roots=len(self.csg_roots), n_csg_nodes=len(self.csg_nodes),
                  n_materials=len(self.materials), n_pat_nodes=len(P), n_programs=len(self.programs),
-                 n_instr=len(self.instr), n_textures=len(self.textures), tex_bytes=off, n_lights=len(lights))
+                 n_instr=len(self.instr), n_textures=len(self.textures), tex_bytes=off, n_lights=len(lights),
+                 n_mesh_tris=n_mesh_tris, n_meshes=len(meshes), n_instances=len(inst_rows))
         cs.leaf_objects = self.leaf_objects
         return cs
 
 
-def compile_scene(world):
-    """World (lights + contains) -> CompiledScene."""
-    c = _Compiler()
+def compile_scene(world, instancing="auto"):
+    """World (lights + contains) -> CompiledScene.  instancing: True = meshes the loader made more than once are kept once, in
+    object space, with an instance per use (a third of the device memory on the dragons; faster in fp32, slower in fp64);
+    False = every copy flattened to world space (what the triangle-update entry points replace rows of); "auto" (default) =
+    instanced only when that keeps AUTO_INSTANCE_SAVED_TRIS triangles off the GPU."""
+    c = _Compiler(instancing)
     for obj in world.contains:
         c.shape(obj, None, False)
     return c.finish(list(world.lights or []))

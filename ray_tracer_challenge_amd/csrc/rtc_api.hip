@@ -373,16 +373,17 @@ struct rtc_scene {
 namespace {
 
 template <class R>
-int upload_real(const rtc_scene_desc& d, const std::vector<double>& node_box, DeviceArena& A, rtc::DScene<R>& S) {
+int upload_real(const rtc_scene_desc& d, const std::vector<double>& quadric_minmax, DeviceArena& A, rtc::DScene<R>& S) {
 #define UP_REAL(field, src, count)                                             \
     do {                                                                       \
         std::vector<R> tmp_ = cast_vec<R>((src), (size_t)(count));             \
         if (int rc_ = A.upload(tmp_.data(), tmp_.size(), &S.field)) return rc_; \
     } while (0)
-    UP_REAL(leaf_minmax, d.leaf_minmax, 2 * (size_t)d.n_leaves);
+    UP_REAL(leaf_minmax, quadric_minmax.data(), quadric_minmax.size());      // one row per cylinder / cone (create_impl), not per leaf
     UP_REAL(xform, d.xform, 12 * (size_t)d.n_xforms);
     UP_REAL(tri_geom, d.tri_geom, 12 * (size_t)d.n_tris);
     UP_REAL(tri_norm, d.tri_norm, 12 * (size_t)d.n_tris);
+    UP_REAL(mesh_norm, d.mesh_norm, 12 * (size_t)d.n_mesh_tris);
     UP_REAL(csg_bbox, d.csg_bbox, 6 * (size_t)d.n_csg_nodes);
     UP_REAL(mat, d.mat, 10 * (size_t)d.n_materials);
     UP_REAL(pat_inv, d.pat_inv, 12 * (size_t)d.n_pat_nodes);
@@ -393,7 +394,6 @@ int upload_real(const rtc_scene_desc& d, const std::vector<double>& node_box, De
     UP_REAL(light_geom, d.light_geom, 9 * (size_t)d.n_lights);
     UP_REAL(light_intensity, d.light_intensity, 3 * (size_t)d.n_lights);
 #undef UP_REAL
-    (void)node_box;
     return 0;
 }
 
@@ -442,7 +442,9 @@ int validate(const rtc_scene_desc& d) {
         if (k < RTC_SPHERE || k > RTC_TRIANGLE) return fail(RTC_ERR_INVALID, "leaf %d: unknown kind %d", i, k);
         if (d.leaf_xform[i] < 0 || d.leaf_xform[i] >= d.n_xforms) return fail(RTC_ERR_INVALID, "leaf %d: xform row out of range", i);
         if (d.leaf_material[i] < 0 || d.leaf_material[i] >= d.n_materials) return fail(RTC_ERR_INVALID, "leaf %d: material out of range", i);
-        if (k == RTC_TRIANGLE && (d.leaf_tri[i] < 0 || d.leaf_tri[i] >= d.n_tris)) return fail(RTC_ERR_INVALID, "leaf %d: triangle row out of range", i);
+        if (k == RTC_TRIANGLE && d.leaf_tri[i] <= -2) {                      // a triangle of an instanced mesh: -2 - (mesh row)
+            if (-2 - (long long)d.leaf_tri[i] >= d.n_mesh_tris) return fail(RTC_ERR_INVALID, "leaf %d: mesh row out of range", i);
+        } else if (k == RTC_TRIANGLE && (d.leaf_tri[i] < 0 || d.leaf_tri[i] >= d.n_tris)) return fail(RTC_ERR_INVALID, "leaf %d: triangle row out of range", i);
     }
     for (int i = 0; i < d.n_tris; i++)
         if (d.tri_leaf[i] < 0 || d.tri_leaf[i] >= d.n_leaves) return fail(RTC_ERR_INVALID, "triangle %d: leaf out of range", i);
@@ -451,6 +453,7 @@ int validate(const rtc_scene_desc& d) {
         int kind = (int)((uint32_t)code >> 28), idx = (int)((uint32_t)code & 0x07FFFFFFu);
         if (kind == RTC_TRIANGLE) { if (idx >= d.n_tris) return fail(RTC_ERR_INVALID, "%s %d: triangle row out of range", what, i); }
         else if (kind == RTC_CSG_ROOT) { if (idx >= d.n_csg_roots) return fail(RTC_ERR_INVALID, "%s %d: CSG root out of range", what, i); }
+        else if (kind == RTC_INSTANCE) { if (idx >= d.n_instances) return fail(RTC_ERR_INVALID, "%s %d: instance out of range", what, i); }
         else if (kind <= RTC_CONE) { if (idx >= d.n_leaves || d.leaf_kind[idx] != kind) return fail(RTC_ERR_INVALID, "%s %d: leaf/kind mismatch", what, i); }
         else return fail(RTC_ERR_INVALID, "%s %d: unknown prim kind %d", what, i, kind);
         return 0;
@@ -463,6 +466,23 @@ int validate(const rtc_scene_desc& d) {
     }
     for (int i = 0; i < d.n_unbounded; i++)
         if (int rc = check_prim(d.unbounded_prim[i], "unbounded", i)) return rc;
+    if (d.n_mesh_tris < 0 || d.n_meshes < 0 || d.n_instances < 0) return fail(RTC_ERR_INVALID, "negative count in scene description");
+    if (d.n_instances > 0 && d.n_csg_roots > 0) return fail(RTC_ERR_UNSUPPORTED, "instanced meshes in a scene with CSG objects (the scene compiler flattens them)");
+    for (int i = 0; i < d.n_instr && d.n_instances > 0; i++)
+        if (d.instr[2 * (size_t)i] == RTC_OP_PERTURB) return fail(RTC_ERR_UNSUPPORTED, "instanced meshes in a scene with perturbed patterns");
+    if (d.n_instances > RTC_MAX_INSTANCES) return fail(RTC_ERR_LIMIT, "%d mesh instances, limit %d (flatten the rest)", d.n_instances, RTC_MAX_INSTANCES);
+    for (int i = 0; i < d.n_meshes; i++) {
+        const int32_t* r = d.mesh_range + 2 * i;
+        if (r[0] < 0 || r[1] < 1 || (long long)r[0] + r[1] > d.n_mesh_tris) return fail(RTC_ERR_INVALID, "mesh %d: rows out of range", i);
+    }
+    for (int i = 0; i < d.n_instances; i++) {
+        const int32_t* r = d.inst + 4 * i;
+        if (r[0] < 0 || r[0] >= d.n_meshes || r[1] < 0 || r[1] >= d.n_xforms || r[3] < 0 || r[3] >= d.n_materials ||
+            r[2] < 0 || (long long)r[2] + d.mesh_range[2 * r[0] + 1] > d.n_leaves)
+            return fail(RTC_ERR_INVALID, "instance %d malformed", i);
+    }
+    for (int i = 0; i < d.n_unbounded; i++)
+        if (((uint32_t)d.unbounded_prim[i] >> 28) == RTC_INSTANCE) return fail(RTC_ERR_INVALID, "an instance cannot be unbounded");
     for (int i = 0; i < d.n_csg_roots; i++) {
         const int32_t* r = d.csg_root + 4 * i;
         if (r[0] < 0 || r[1] < 1 || r[0] + r[1] > d.n_csg_nodes || r[2] < 0 || r[3] > d.n_leaves || r[2] > r[3])
@@ -608,8 +628,18 @@ int create_impl(const rtc_scene_desc& d, rtc_scene* sc) {
     UP(leaf_kind, d.leaf_kind, d.n_leaves);
     UP(leaf_xform, d.leaf_xform, d.n_leaves);
     UP(leaf_material, d.leaf_material, d.n_leaves);
-    UP(leaf_tri, d.leaf_tri, d.n_leaves);
-    UP(leaf_closed, d.leaf_closed, d.n_leaves);
+    // minimum / maximum / closed exist for cylinders and cones only: one row each in compact tables, found through the leaf's
+    // (otherwise unused) leaf_tri entry -- per-leaf arrays of them were 28 bytes a leaf, 4 MB of the dragons' device memory
+    std::vector<int32_t> leaf_tri_dev(d.leaf_tri, d.leaf_tri + d.n_leaves), quadric_closed;
+    std::vector<double> quadric_minmax;
+    for (int i = 0; i < d.n_leaves; i++)
+        if (d.leaf_kind[i] == RTC_CYLINDER || d.leaf_kind[i] == RTC_CONE) {
+            leaf_tri_dev[i] = (int32_t)quadric_closed.size();
+            quadric_minmax.push_back(d.leaf_minmax[2 * (size_t)i]); quadric_minmax.push_back(d.leaf_minmax[2 * (size_t)i + 1]);
+            quadric_closed.push_back(d.leaf_closed[i]);
+        }
+    UP(leaf_tri, leaf_tri_dev.data(), leaf_tri_dev.size());
+    UP(leaf_closed, quadric_closed.data(), quadric_closed.size());
     UP(tri_leaf, d.tri_leaf, d.n_tris);
     UP(bvh_prims, prims.data(), prims.size());
     if (int rc_ = sc->tbvh_mem.upload(tb_leaf.data(), tb_leaf.size(), &S.tb_leaf)) return rc_;
@@ -724,8 +754,87 @@ int create_impl(const rtc_scene_desc& d, rtc_scene* sc) {
         std::vector<float> g32 = cast_vec<float>(tb_geom.data(), tb_geom.size());
         if (int rc = sc->tbvh_mem.upload(g32.data(), g32.size(), &sc->d32.tb_geom)) return rc;
     }
-    if (int rc = upload_real<double>(d, bvh.box, sc->mem64, sc->d64)) return rc;
-    if (int rc = upload_real<float>(d, bvh.box, sc->mem32, sc->d32)) return rc;
+    // ---- instanced meshes: one tree and one set of rows per mesh, in its object space ----
+    if (d.n_instances > 0) {
+        std::vector<rtc::BvhNode4> mnodes;
+        std::vector<double> mb_geom(12 * (size_t)d.n_mesh_tris);
+        std::vector<int32_t> mb_leaf((size_t)d.n_mesh_tris);
+        std::vector<int32_t> mesh_root((size_t)d.n_meshes);
+        std::vector<float> mesh_box(6 * (size_t)d.n_meshes), mesh_far((size_t)d.n_meshes);
+        const double W = sc->max_abs;                  // rays start inside [-W, W]^3 (farther cameras: the FAR variants re-base)
+        for (int m = 0; m < d.n_meshes; m++) {
+            const int r0 = d.mesh_range[2 * m], n = d.mesh_range[2 * m + 1];
+            std::vector<rtc::Aabb> boxes((size_t)n);
+            double max_abs_obj = 0;
+            for (int i = 0; i < n; i++) {
+                const double* g = d.mesh_geom + 12 * (size_t)(r0 + i);
+                for (int k = 0; k < 3; k++) {
+                    const double p1 = g[k], p2 = g[k] + g[3 + k], p3 = g[k] + g[6 + k];
+                    boxes[i].lo[k] = std::min(p1, std::min(p2, p3)); boxes[i].hi[k] = std::max(p1, std::max(p2, p3));
+                    max_abs_obj = std::max(max_abs_obj, std::max(std::fabs(boxes[i].lo[k]), std::fabs(boxes[i].hi[k])));
+                }
+            }
+            // where rays that walk this tree can start, in its object space: the corners of the scene's extent through every instance's transform
+            for (int q = 0; q < d.n_instances; q++) {
+                if (d.inst[4 * q] != m) continue;
+                const double* M = d.xform + 12 * (size_t)d.inst[4 * q + 1];
+                for (int c = 0; c < 8; c++) {
+                    const double x = (c & 1) ? W : -W, y = (c & 2) ? W : -W, z = (c & 4) ? W : -W;
+                    for (int k = 0; k < 3; k++) max_abs_obj = std::max(max_abs_obj, std::fabs(M[4 * k] * x + M[4 * k + 1] * y + M[4 * k + 2] * z + M[4 * k + 3]));
+                }
+            }
+            if (!std::isfinite(max_abs_obj)) return fail(RTC_ERR_INVALID, "mesh %d: coordinates are not finite", m);
+            rtc::Bvh mb = rtc::build_bvh(boxes, tri_leaf, RTC_BVH_STACK - 2);
+            if (mb.depth > RTC_BVH_STACK - 1) return fail(RTC_ERR_LIMIT, "BVH depth exceeds traversal stack");
+            rtc::Bvh4 m4 = rtc::collapse_bvh4(mb, RTC_BVH_STACK - 1);
+            if (m4.stack_need > RTC_BVH_STACK - 1) return fail(RTC_ERR_LIMIT, "four-wide mesh BVH needs %d stack entries", m4.stack_need);
+            std::vector<float> b4 = pad_boxes<float>(m4.box, RTC_PAD_OF_EXTENT * max_abs_obj);
+            const int node_base = (int)mnodes.size();
+            mesh_root[m] = node_base;
+            float* rb = &mesh_box[6 * (size_t)m];
+            for (int a = 0; a < 3; a++) { rb[a] = 3.0e38f; rb[3 + a] = -3.0e38f; }
+            for (int i = 0; i < m4.n_nodes(); i++) {
+                rtc::BvhNode4 nd;
+                memcpy(nd.box, &b4[24 * (size_t)i], 24 * sizeof(float));
+                for (int k = 0; k < 4; k++) {
+                    int32_t c = m4.child[4 * (size_t)i + k];
+                    if (c >= 0) c += node_base;
+                    else if (c != RTC_EMPTY_CHILD) { const int code = ~c; c = ~((((code >> 4) + r0) << 4) | (code & 15)); }      // rows of this mesh start at r0
+                    nd.child[k] = c; nd.src[k] = -1;
+                    if (i == 0 && c != RTC_EMPTY_CHILD)
+                        for (int a = 0; a < 3; a++) { rb[a] = std::min(rb[a], nd.box[6 * k + a]); rb[3 + a] = std::max(rb[3 + a], nd.box[6 * k + 3 + a]); }
+                }
+                mnodes.push_back(nd);
+            }
+            mesh_far[m] = (float)(2.0 * std::max(max_abs_obj, 1e-30));
+            for (int i = 0; i < n; i++) {
+                memcpy(&mb_geom[12 * (size_t)(r0 + i)], d.mesh_geom + 12 * (size_t)(r0 + mb.order[i]), 12 * sizeof(double));
+                mb_leaf[(size_t)r0 + i] = mb.order[i];
+            }
+            sc->bvh_nodes += m4.n_nodes(); sc->bvh_depth = std::max(sc->bvh_depth, mb.depth);
+        }
+        std::vector<int32_t> inst(8 * (size_t)d.n_instances, 0);
+        std::vector<float> inst_box(6 * (size_t)d.n_instances), inst_far((size_t)d.n_instances);
+        for (int q = 0; q < d.n_instances; q++) {
+            const int m = d.inst[4 * q];
+            inst[8 * q] = mesh_root[m]; inst[8 * q + 1] = d.inst[4 * q + 1]; inst[8 * q + 2] = d.inst[4 * q + 2];
+            inst[8 * q + 3] = d.mesh_range[2 * m]; inst[8 * q + 4] = d.inst[4 * q + 3];
+            memcpy(&inst_box[6 * (size_t)q], &mesh_box[6 * (size_t)m], 6 * sizeof(float));
+            inst_far[q] = mesh_far[m];
+        }
+        if (int rc = A.upload(mnodes.data(), mnodes.size(), &S.mnodes4)) return rc;
+        if (int rc = A.upload(mb_leaf.data(), mb_leaf.size(), &S.mb_leaf)) return rc;
+        if (int rc = A.upload(inst.data(), inst.size(), &S.inst)) return rc;
+        if (int rc = A.upload(inst_box.data(), inst_box.size(), &S.inst_box)) return rc;
+        if (int rc = A.upload(inst_far.data(), inst_far.size(), &S.inst_far)) return rc;
+        if (int rc = sc->mem64.upload(mb_geom.data(), mb_geom.size(), &sc->d64.mb_geom)) return rc;
+        std::vector<float> g32 = cast_vec<float>(mb_geom.data(), mb_geom.size());
+        if (int rc = sc->mem32.upload(g32.data(), g32.size(), &sc->d32.mb_geom)) return rc;
+        S.n_inst = d.n_instances;
+        F.n_inst = S.n_inst; F.mnodes4 = S.mnodes4; F.mb_leaf = S.mb_leaf; F.inst = S.inst; F.inst_box = S.inst_box; F.inst_far = S.inst_far;
+    }
+    if (int rc = upload_real<double>(d, quadric_minmax, sc->mem64, sc->d64)) return rc;
+    if (int rc = upload_real<float>(d, quadric_minmax, sc->mem32, sc->d32)) return rc;
     if ((sc->d64.n_bvh_nodes > 0 && (!sc->d64.nodes || !sc->d64.bvh_prims || !sc->d32.nodes)) ||
         (sc->d64.n_tnodes > 0 && (!sc->d64.tnodes || !sc->d64.tnodes4 || !sc->d32.tnodes4 || !sc->d64.tb_geom || !sc->d64.tb_leaf || !sc->d32.tnodes || !sc->d32.tb_geom)))
         return fail(RTC_ERR_HIP, "internal: BVH arrays missing on the device");
@@ -985,6 +1094,7 @@ int debug_sync(hipStream_t stream, const char* what, unsigned grid_x, const rtc:
 void launch_trace(rtc_scene* scene, const rtc_camera* cam, const rtc::DFrame& F, dim3 grid, int precision, bool prof, double eps, double eps_rel,
                   hipStream_t stream, bool two_waves = false, int feedback_stage = 0) {
     const bool csg = scene->has_csg;
+    const int mode = csg ? (scene->has_csg_stream ? 2 : 1) : (scene->d64.n_inst > 0 ? 3 : 0);       // trace_kernel's CSG parameter
     // `grid` counts RTC_BLOCK-thread blocks (4 entries of the launch order each); the variants without CSG run one entry per workgroup
     const dim3 block(csg ? RTC_BLOCK_CSG : RTC_BLOCK_PLAIN);
     grid = dim3(grid.x * (RTC_BLOCK / block.x));
@@ -994,7 +1104,7 @@ void launch_trace(rtc_scene* scene, const rtc_camera* cam, const rtc::DFrame& F,
     const bool repl = F.replicas != 0 && !prof;
     {
         rtc_launch_info& L = scene->last_launch;
-        L.precision = precision; L.csg = !csg ? 0 : scene->has_csg_stream ? 2 : 1; L.far_camera = far_cam; L.replicas = repl; L.counting_work = prof;
+        L.precision = precision; L.csg = mode; L.far_camera = far_cam; L.replicas = repl; L.counting_work = prof;
         L.waves_per_simd = csg ? 2 : precision == 64 ? ((two_waves && !prof) ? 2 : RTC_WAVES_F64) : RTC_WAVES_F32;
         L.workgroup_threads = (int32_t)block.x; L.workgroups = (int32_t)grid.x; L.n_units = F.n_units; L.n_entries = F.order ? F.n_entries : F.n_units;
         L.feedback_stage = feedback_stage;
@@ -1013,9 +1123,9 @@ void launch_trace(rtc_scene* scene, const rtc_camera* cam, const rtc::DFrame& F,
 #endif
     if (precision == 64) {
         // the variants of rtc_trace_f64.hip (built without machine LICM, which parks hoisted fp64 constants in scratch)
-        rtc::launch_trace_f64(!csg ? 0 : scene->has_csg_stream ? 2 : 1, prof, far_cam, repl, two_waves, grid, stream, scene->d64, make_camera<double>(*cam), F, eps, eps_rel);
+        rtc::launch_trace_f64(mode, prof, far_cam, repl, two_waves, grid, stream, scene->d64, make_camera<double>(*cam), F, eps, eps_rel);
     } else {
-        if (!csg) RTC_LAUNCH_FAR(float, 0, scene->d32); else RTC_LAUNCH_CSG12(float, scene->d32);
+        if (mode == 3) RTC_LAUNCH_FAR(float, 3, scene->d32); else if (!csg) RTC_LAUNCH_FAR(float, 0, scene->d32); else RTC_LAUNCH_CSG12(float, scene->d32);
     }
 #undef RTC_LAUNCH_CSG12
 #undef RTC_LAUNCH_FAR

@@ -151,7 +151,8 @@ struct alignas(128) BvhNode4 { float box[24]; int32_t child[4]; int32_t src[4]; 
 template <class R> struct DScene {
     int32_t n_leaves;
     const int32_t* leaf_kind; const int32_t* leaf_xform; const int32_t* leaf_material;
-    const int32_t* leaf_tri; const int32_t* leaf_closed; const R* leaf_minmax;
+    const int32_t* leaf_tri;       // triangles: row of tri_geom / tri_norm, or -2 - row of mesh_norm (instanced); cylinders / cones: row of the two tables below
+    const int32_t* leaf_closed; const R* leaf_minmax;       // [cylinders + cones], [..][2]
     const R* xform;
     const R* tri_geom; const R* tri_norm; const int32_t* tri_leaf;
     int32_t n_bvh_nodes;           // 0 = no bounded items
@@ -168,6 +169,15 @@ template <class R> struct DScene {
     const BvhNode4* tnodes4;       // the same tree four-wide: what rays walk (tnodes is what builds and refits work on)
     const R* tb_geom;              // [n_tris][12] tri_geom rows in BVH leaf order
     const int32_t* tb_leaf;        // [n_tris] leaf id, bit 31 set = does not cast shadows
+    // instanced meshes (rtc_scene_desc::inst): one four-wide tree and one set of rows per mesh, in the mesh's object space
+    int32_t n_inst;
+    const int32_t* inst;           // [n_inst][8] root node (mnodes4), xform row, first leaf, first row of mesh_norm, material, 0, 0, 0
+    const float* inst_box;         // [n_inst][6] the (padded) box of the mesh's tree, object space: where far rays are re-based
+    const float* inst_far;         // [n_inst] far_origin in the mesh's object space
+    const BvhNode4* mnodes4;
+    const R* mb_geom;              // [n_mesh_tris][12] rows in the order of their mesh's tree
+    const int32_t* mb_leaf;        // [n_mesh_tris] row within the mesh = leaf - first leaf of the instance
+    const R* mesh_norm;            // [n_mesh_tris][12] object-space vertex normals, row order
     int32_t n_unbounded; const int32_t* unbounded_prims;
     const int32_t* csg_root; const int32_t* csg_node; const R* csg_bbox;
     const R* mat; const int32_t* mat_shadow; const int32_t* mat_program;
@@ -253,8 +263,11 @@ enum { W_NODE = 0, W_TRI = 1, W_LEAF = 2, W_CSG = 3, W_SHADE = 4, W_LIGHT = 5, W
 // REPL = the launch order has split parts whose pixels are traced by several lanes each (DFrame::replicas): only those
 // launches' variants carry the replicated light loop (inlined into every variant it cost the fp64 kernel 18 more spilled
 // registers: teapot +9 %, earth +15 % at 1080p, where nothing is split).
-template <bool PROF, bool CSG = true, bool FAR = false, bool STREAM = false, bool REPL = false> struct Counters {
+// INST = the scene holds instanced meshes (and no CSG objects: the scene compiler flattens them otherwise): only those scenes'
+// variants carry the walk through instances (traverse) and what it keeps live.
+template <bool PROF, bool CSG = true, bool FAR = false, bool STREAM = false, bool REPL = false, bool INST = false> struct Counters {
     static constexpr bool kCsg = CSG;
+    static constexpr bool kInst = INST;
     static constexpr bool kFar = FAR;
     static constexpr bool kStream = CSG && STREAM;
     static constexpr bool kReplicas = REPL;
@@ -437,8 +450,11 @@ template <class R> __device__ __forceinline__ int leaf_hits(const DScene<R>& S, 
     }
     int n;
     if (kind == RTC_SPHERE) n = sphere_hits(r, t);
-    else if (kind == RTC_CYLINDER) n = quadric_hits<R, false>(r, S.leaf_minmax[2 * leaf], S.leaf_minmax[2 * leaf + 1], S.leaf_closed[leaf] != 0, t);
-    else n = quadric_hits<R, true>(r, S.leaf_minmax[2 * leaf], S.leaf_minmax[2 * leaf + 1], S.leaf_closed[leaf] != 0, t);
+    else {
+        const int q = S.leaf_tri[leaf];             // a cylinder's / cone's row of the minimum / maximum / closed tables
+        if (kind == RTC_CYLINDER) n = quadric_hits<R, false>(r, S.leaf_minmax[2 * q], S.leaf_minmax[2 * q + 1], S.leaf_closed[q] != 0, t);
+        else n = quadric_hits<R, true>(r, S.leaf_minmax[2 * q], S.leaf_minmax[2 * q + 1], S.leaf_closed[q] != 0, t);
+    }
     if (sizeof(R) == 4)
         for (int k = 0; k < n; k++) t[k] += shift;
     return n;
@@ -717,10 +733,13 @@ __device__ __forceinline__ bool traverse_bvh(const DScene<R>& S, const Ray<R>& r
 // bits) are sorted as unsigned integers by a five-exchange network, the nearest is entered, the others are pushed farthest
 // first.  The order changes no result (every child that is hit is visited unless the limit has shrunk below its entry
 // distance by then -- the visitor's own comparison decides, as in the binary walk).
-template <class R, class V>
-__device__ __forceinline__ bool traverse_bvh4(const DScene<R>& S, const Ray<R>& ray, R tlo, V& vis, int* stack /* LDS, stride = threads per workgroup */) {
+// INST: the tree of an instanced mesh (`ray` already in its object space; triangles go to vis.tri<true>): nodes, root and the
+// box / far_origin for re-basing are the instance's.
+template <class R, class V, bool INST = false>
+__device__ __forceinline__ bool traverse_bvh4(const DScene<R>& S, const Ray<R>& ray, R tlo, V& vis, int* stack /* LDS, stride = threads per workgroup */,
+                                              int inst = 0, int root = 0) {
     constexpr int kStride = std::remove_reference_t<decltype(vis.cnt)>::kBlock;
-    const BvhNode4* __restrict__ nodes = S.tnodes4;
+    const BvhNode4* __restrict__ nodes = INST ? S.mnodes4 : S.tnodes4;
     float ix = 1.0f / (float)ray.d.x, iy = 1.0f / (float)ray.d.y, iz = 1.0f / (float)ray.d.z;
     if (!(fabsf(ix) <= 1e30f)) ix = copysignf(1e30f, (float)ray.d.x);
     if (!(fabsf(iy) <= 1e30f)) iy = copysignf(1e30f, (float)ray.d.y);
@@ -728,8 +747,8 @@ __device__ __forceinline__ bool traverse_bvh4(const DScene<R>& S, const Ray<R>& 
     float base32 = 0.0f, lim_pad = 0.0f;
     float ox = -(float)ray.o.x * ix, oy = -(float)ray.o.y * iy, oz = -(float)ray.o.z * iz;
     float tlo32 = (float)tlo;
-    if (V::Cnt::kFar && fmaxf(fmaxf(fabsf((float)ray.o.x), fabsf((float)ray.o.y)), fabsf((float)ray.o.z)) > S.far_origin) {      // see traverse_bvh
-        const float* rb = S.tbox;
+    if (V::Cnt::kFar && fmaxf(fmaxf(fabsf((float)ray.o.x), fabsf((float)ray.o.y)), fabsf((float)ray.o.z)) > (INST ? S.inst_far[inst] : S.far_origin)) {      // see traverse_bvh
+        const float* rb = INST ? S.inst_box + 6 * inst : S.tbox;
         const float px = (float)ray.o.x, py = (float)ray.o.y, pz = (float)ray.o.z;
         const float x0 = (rb[0] - px) * ix, x1 = (rb[3] - px) * ix, y0 = (rb[1] - py) * iy, y1 = (rb[4] - py) * iy, z0 = (rb[2] - pz) * iz, z1 = (rb[5] - pz) * iz;
         float enter = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
@@ -743,7 +762,7 @@ __device__ __forceinline__ bool traverse_bvh4(const DScene<R>& S, const Ray<R>& 
         }
     }
     int sp = 0;
-    int node = 0;
+    int node = INST ? root : 0;
     while (true) {
         if (node >= 0) {
             vis.cnt.work(W_NODE);
@@ -789,7 +808,7 @@ __device__ __forceinline__ bool traverse_bvh4(const DScene<R>& S, const Ray<R>& 
             int first = code >> 4, count = (code & 15) + 1;
             const bool uniform = __builtin_amdgcn_ballot_w64(code != __builtin_amdgcn_readfirstlane(code)) == 0ull;
             for (int i = 0; i < count; i++)
-                if (vis.tri(first + i, uniform)) return true;
+                if (vis.template tri<INST>(first + i, uniform)) return true;
         }
         if (sp == 0) return false;
         sp--;
@@ -837,9 +856,31 @@ template <class R, class V> __device__ __forceinline__ void traverse_objects(con
 template <class R, class V> __device__ __forceinline__ void traverse_tris(const DScene<R>& S, const Ray<R>& ray, R tlo, V& vis, int* stack) {
     if (S.n_tnodes > 0) traverse_bvh4<R, V>(S, ray, tlo, vis, stack);
 }
+// Instances of meshes are prims of the object BVH: the visitors do not walk a mesh where they meet its box (the outer walk's
+// state would stay live through the inner one) but note the instance -- a byte each in one 64-bit word, in the order met,
+// i.e. roughly near to far -- and the meshes are walked here afterwards, the ray taken to each one's object space by the
+// instance's collapsed transform (direction not renormalised, so t is the world's t: shapes.py:271-273, 1447-1448).
+struct PendingInstances {
+    unsigned long long list; int n;
+    __device__ __forceinline__ void clear() { list = 0ull; n = 0; }
+    __device__ __forceinline__ void add(int idx) { if (n < RTC_MAX_INSTANCES) { list |= (unsigned long long)(idx + 1) << (8 * n); n++; } }
+};
 template <class R, class V> __device__ __forceinline__ void traverse(const DScene<R>& S, const Ray<R>& ray, R tlo, V& vis, int* stack) {
     traverse_objects(S, ray, tlo, vis, stack);
     if (!vis.done()) traverse_tris(S, ray, tlo, vis, stack);
+    if (V::Cnt::kInst) {
+        unsigned long long list = vis.pending.list;
+        vis.pending.clear();
+        while (list != 0ull && !vis.done()) {
+            const int inst = (int)(list & 255ull) - 1;
+            list >>= 8;
+            const int32_t* I = S.inst + 8 * inst;
+            const R* m = S.xform + 12 * (size_t)I[1];
+            vis.oray.o = xpoint(m, ray.o); vis.oray.d = xvector(m, ray.d);
+            vis.inst_leaf0 = I[2];
+            traverse_bvh4<R, V, true>(S, vis.oray, tlo, vis, stack, inst, I[0]);
+        }
+    }
 }
 
 // hit(intersect_world(ray)) (renderer.py:75-79, shapes.py:1422-1425): smallest t > 0
@@ -847,21 +888,23 @@ template <class R, class CNT> struct NearestVisitor {
     typedef CNT Cnt;
     const DScene<R>& S; const Ray<R>& ray; CNT& cnt;
     R best; int leaf; R u, v;
-    __device__ __forceinline__ NearestVisitor(const DScene<R>& s, const Ray<R>& r, CNT& c) : S(s), ray(r), cnt(c), best(inf_<R>()), leaf(-1), u(0), v(0) {}
+    PendingInstances pending; Ray<R> oray; int inst_leaf0;       // traverse(): the instances met, the ray in the object space of the one being walked
+    __device__ __forceinline__ NearestVisitor(const DScene<R>& s, const Ray<R>& r, CNT& c) : S(s), ray(r), cnt(c), best(inf_<R>()), leaf(-1), u(0), v(0) { pending.clear(); }
     static constexpr bool kFlatRootBox = true;
     static constexpr bool kUnordered = false;
     __device__ __forceinline__ R limit() const { return best; }
     __device__ __forceinline__ bool done() const { return false; }
-    __device__ __forceinline__ bool tri(int pos, bool uniform = false) {
+    template <bool INST> __device__ __forceinline__ bool tri(int pos, bool uniform = false) {
         R t, tu, tv;
         cnt.work(W_TRI);
-        if (tri_hit(S.tb_geom + 12 * (size_t)pos, ray, t, tu, tv, uniform) && t > R(0) && t < best) {
-            best = t; leaf = S.tb_leaf[pos] & 0x7FFFFFFF; u = tu; v = tv;
+        if (tri_hit((INST ? S.mb_geom : S.tb_geom) + 12 * (size_t)pos, INST ? oray : ray, t, tu, tv, uniform) && t > R(0) && t < best) {
+            best = t; leaf = INST ? inst_leaf0 + S.mb_leaf[pos] : (S.tb_leaf[pos] & 0x7FFFFFFF); u = tu; v = tv;
         }
         return false;
     }
     __device__ __forceinline__ bool prim(int32_t code) {
         PrimCode p(code);
+        if (CNT::kInst && p.kind == RTC_INSTANCE) { pending.add(p.idx); return false; }
         if (CNT::kStream && p.kind == RTC_CSG_ROOT && csg_streamed(S.csg_root, p.idx)) {
             cnt.work(W_CSG);
             struct First { R t; int leaf; __device__ bool operator()(R tt, int l) { if (tt > R(0)) { t = tt; leaf = l; return true; } return false; } } first = {R(0), -1};
@@ -897,19 +940,22 @@ template <class R, class CNT> struct NearestVisitor {
 template <class R, class CNT> struct ShadowVisitor {
     typedef CNT Cnt;
     const DScene<R>& S; const Ray<R>& ray; CNT& cnt; R dist; bool shadowed;
-    __device__ __forceinline__ ShadowVisitor(const DScene<R>& s, const Ray<R>& r, R d, CNT& c) : S(s), ray(r), cnt(c), dist(d), shadowed(false) {}
+    PendingInstances pending; Ray<R> oray; int inst_leaf0;
+    __device__ __forceinline__ ShadowVisitor(const DScene<R>& s, const Ray<R>& r, R d, CNT& c) : S(s), ray(r), cnt(c), dist(d), shadowed(false) { pending.clear(); }
     static constexpr bool kFlatRootBox = false;    // shadow rays start on the objects: most of them are inside the box anyway
     static constexpr bool kUnordered = true;
     __device__ __forceinline__ R limit() const { return dist; }
     __device__ __forceinline__ bool done() const { return shadowed; }
-    __device__ __forceinline__ bool tri(int pos, bool uniform = false) {
+    template <bool INST> __device__ __forceinline__ bool tri(int pos, bool uniform = false) {
         R t, tu, tv;
         cnt.work(W_TRI);
-        if (tri_hit(S.tb_geom + 12 * (size_t)pos, ray, t, tu, tv, uniform) && t > R(0) && t < dist && S.tb_leaf[pos] >= 0) { shadowed = true; return true; }
+        // (an instance that casts no shadow is never walked by a shadow ray, prim())
+        if (tri_hit((INST ? S.mb_geom : S.tb_geom) + 12 * (size_t)pos, INST ? oray : ray, t, tu, tv, uniform) && t > R(0) && t < dist && (INST || S.tb_leaf[pos] >= 0)) { shadowed = true; return true; }
         return false;
     }
     __device__ __forceinline__ bool prim(int32_t code) {
         PrimCode p(code);
+        if (CNT::kInst && p.kind == RTC_INSTANCE) { if (!p.noshadow) pending.add(p.idx); return false; }
         if (CNT::kStream && p.kind == RTC_CSG_ROOT && csg_streamed(S.csg_root, p.idx)) {
             cnt.work(W_CSG);
             struct Occluder {
@@ -953,18 +999,19 @@ template <class R, class CNT> struct ContainerVisitor {
     R t_hit; int x_leaf;
     bool x_odd; R x_last;
     int y_leaf; R y_last;
+    PendingInstances pending; Ray<R> oray; int inst_leaf0;
     __device__ __forceinline__ ContainerVisitor(const DScene<R>& s, const Ray<R>& r, R th, int xl, CNT& c)
-        : S(s), ray(r), cnt(c), t_hit(th), x_leaf(xl), x_odd(false), x_last(-inf_<R>()), y_leaf(-1), y_last(-inf_<R>()) {}
+        : S(s), ray(r), cnt(c), t_hit(th), x_leaf(xl), x_odd(false), x_last(-inf_<R>()), y_leaf(-1), y_last(-inf_<R>()) { pending.clear(); }
     static constexpr bool kFlatRootBox = true;
     static constexpr bool kUnordered = true;          // the far bound is fixed and every leaf in range is visited: no order among children needed
     __device__ __forceinline__ R limit() const { return t_hit; }
     __device__ __forceinline__ bool done() const { return false; }
-    __device__ __forceinline__ bool tri(int pos, bool = false) {
+    template <bool INST> __device__ __forceinline__ bool tri(int pos, bool = false) {
         R t, tu, tv;
-        const int leaf = S.tb_leaf[pos] & 0x7FFFFFFF;
+        const int leaf = INST ? inst_leaf0 + S.mb_leaf[pos] : (S.tb_leaf[pos] & 0x7FFFFFFF);
         if (leaf == x_leaf) return false;        // the hit triangle's one intersection is the hit itself: nothing precedes it
         cnt.work(W_TRI);
-        if (tri_hit(S.tb_geom + 12 * (size_t)pos, ray, t, tu, tv) && t < t_hit) account(leaf, 1, t);
+        if (tri_hit((INST ? S.mb_geom : S.tb_geom) + 12 * (size_t)pos, INST ? oray : ray, t, tu, tv) && t < t_hit) account(leaf, 1, t);
         return false;
     }
     // Which intersections of the hit leaf X precede the hit must not hang on this pass recomputing the hit's t to the
@@ -977,6 +1024,7 @@ template <class R, class CNT> struct ContainerVisitor {
     }
     __device__ __forceinline__ bool prim(int32_t code) {
         PrimCode p(code);
+        if (CNT::kInst && p.kind == RTC_INSTANCE) { pending.add(p.idx); return false; }
         if (CNT::kStream && p.kind == RTC_CSG_ROOT && csg_streamed(S.csg_root, p.idx)) {
             cnt.work(W_CSG);
             // Where the root's sorted list is cut: at X's entry nearest t_hit if X belongs to this root (first pass: its
@@ -1054,7 +1102,15 @@ template <class R, class CNT> struct ContainerVisitor {
 template <class R> __device__ __forceinline__ V3<R> normal_at(const DScene<R>& S, int leaf, V3<R> wp, R hu, R hv) {
     int kind = S.leaf_kind[leaf];
     if (kind == RTC_TRIANGLE) {
-        const R* nn = S.tri_norm + 12 * (size_t)S.leaf_tri[leaf];
+        const int row = S.leaf_tri[leaf];
+        if (row <= -2) {
+            // a triangle of an instanced mesh: the object-space normal (shapes.py:857-858) taken to world space by the transposed
+            // collapsed transform (normal_to_world, shapes.py:288-296) -- what the world-space rows below hold ready-made
+            const R* nn = S.mesh_norm + 12 * (size_t)(-2 - row);
+            V3<R> n1 = mk<R>(nn[0], nn[1], nn[2]), n2 = mk<R>(nn[3], nn[4], nn[5]), n3 = mk<R>(nn[6], nn[7], nn[8]);
+            return normalize(xtvector(S.xform + 12 * (size_t)S.leaf_xform[leaf], n2 * hu + n3 * hv + n1 * (R(1) - hu - hv)));
+        }
+        const R* nn = S.tri_norm + 12 * (size_t)row;
         V3<R> n1 = mk<R>(nn[0], nn[1], nn[2]), n2 = mk<R>(nn[3], nn[4], nn[5]), n3 = mk<R>(nn[6], nn[7], nn[8]);
         return normalize(n2 * hu + n3 * hv + n1 * (R(1) - hu - hv));
     }
@@ -1074,7 +1130,8 @@ template <class R> __device__ __forceinline__ V3<R> normal_at(const DScene<R>& S
     }
     default: {   // cylinder / cone: caps by `dist < 1` in both (shapes.py:676-687, 767-774)
         R dist = p.x * p.x + p.z * p.z;
-        R minimum = S.leaf_minmax[2 * leaf], maximum = S.leaf_minmax[2 * leaf + 1];
+        const int q = S.leaf_tri[leaf];
+        R minimum = S.leaf_minmax[2 * q], maximum = S.leaf_minmax[2 * q + 1];
         // fp32 only: a hit point brought back to object space is off by ~1e-6 x its world coordinates, which is the
         // reference's whole EPSILON -- a point on a cap would pass for a wall point and get the wall's normal
         const R cap_eps = sizeof(R) == 4 ? R(1e-4) : RTC_EPS;
@@ -1664,9 +1721,9 @@ template <class R> __device__ __forceinline__ Ray<R> ray_for_pixel(const DCamera
 }
 
 // block-level reduction of the ray / work counters, then a few atomics per block
-template <bool PROF, bool CSG, bool FAR, bool STREAM, bool REPL>
-__device__ __forceinline__ void flush_counters(Counters<PROF, CSG, FAR, STREAM, REPL>& cnt, const DFrame& F, unsigned int* red /* LDS, >= 5 * waves per workgroup */) {
-    constexpr int kWaves = Counters<PROF, CSG, FAR, STREAM, REPL>::kBlock / 64;
+template <bool PROF, bool CSG, bool FAR, bool STREAM, bool REPL, bool INST>
+__device__ __forceinline__ void flush_counters(Counters<PROF, CSG, FAR, STREAM, REPL, INST>& cnt, const DFrame& F, unsigned int* red /* LDS, >= 5 * waves per workgroup */) {
+    constexpr int kWaves = Counters<PROF, CSG, FAR, STREAM, REPL, INST>::kBlock / 64;
     if (!PROF && (!CSG || RTC_CSG_SLOTS) && F.rays && F.work) {          // per-wave slots (DFrame::work)
         uint32_t* parts = reinterpret_cast<uint32_t*>(F.work);
         const int ln = threadIdx.x & 63;
@@ -1702,7 +1759,7 @@ __device__ __forceinline__ void flush_counters(Counters<PROF, CSG, FAR, STREAM, 
         }
     }
 }
-template <bool PROF, bool CSG, bool FAR, bool STREAM, bool REPL> __device__ __forceinline__ void zero_counters(Counters<PROF, CSG, FAR, STREAM, REPL>& cnt) {
+template <bool PROF, bool CSG, bool FAR, bool STREAM, bool REPL, bool INST> __device__ __forceinline__ void zero_counters(Counters<PROF, CSG, FAR, STREAM, REPL, INST>& cnt) {
     cnt.rep = 0; cnt.nrep = 1;
     for (int k = 0; k < 5; k++) cnt.c[k] = 0;
     for (int k = 0; k < (PROF ? W_COUNT : 1); k++) cnt.w[k] = 0;

@@ -18,21 +18,24 @@ void launch_trace_f64(int csg, bool prof, bool far_cam, bool repl, bool two_wave
     const dim3 block(csg ? RTC_BLOCK_CSG : RTC_BLOCK_PLAIN);
 #define RTC_F64(PROF, CSG, FAR, REPL, W) hipLaunchKernelGGL((trace_kernel<double, PROF, CSG, FAR, REPL, W>), grid, block, 0, stream, S, cam, F, eps, eps_rel)
     // without CSG: two register budgets (launch() times them per view); with: one
-#define RTC_F64_W(FAR, REPL) do { if (two_waves) RTC_F64(false, 0, FAR, REPL, 2); else RTC_F64(false, 0, FAR, REPL, RTC_WAVES_F64); } while (0)
+#define RTC_F64_W(FAR, REPL) do { if (csg == 3) { if (two_waves) RTC_F64(false, 3, FAR, REPL, 2); else RTC_F64(false, 3, FAR, REPL, RTC_WAVES_F64); } \
+    else if (two_waves) RTC_F64(false, 0, FAR, REPL, 2); else RTC_F64(false, 0, FAR, REPL, RTC_WAVES_F64); } while (0)
+#define RTC_F64_PROF(FAR) do { if (csg == 3) RTC_F64(true, 3, FAR, false, RTC_WAVES_F64); else RTC_F64(true, 0, FAR, false, RTC_WAVES_F64); } while (0)
 #define RTC_F64_CSG(CSG, FAR) do { if (prof) RTC_F64(true, CSG, FAR, false, RTC_WAVES_OF(double, CSG)); else if (repl) RTC_F64(false, CSG, FAR, true, RTC_WAVES_OF(double, CSG)); \
     else RTC_F64(false, CSG, FAR, false, RTC_WAVES_OF(double, CSG)); } while (0)
 #ifdef RTC_DEV_PLAIN_ONLY   /* development builds: no far-camera variants, no CSG */
-    (void)far_cam; (void)csg;
-    if (prof) RTC_F64(true, 0, false, false, RTC_WAVES_F64);
+    (void)far_cam;
+    if (prof) RTC_F64_PROF(false);
     else if (repl) RTC_F64_W(false, true);
     else RTC_F64_W(false, false);
 #else
     if (csg == 1) { if (far_cam) RTC_F64_CSG(1, true); else RTC_F64_CSG(1, false); }
     else if (csg == 2) { if (far_cam) RTC_F64_CSG(2, true); else RTC_F64_CSG(2, false); }
-    else if (prof) { if (far_cam) RTC_F64(true, 0, true, false, RTC_WAVES_F64); else RTC_F64(true, 0, false, false, RTC_WAVES_F64); }
+    else if (prof) { if (far_cam) RTC_F64_PROF(true); else RTC_F64_PROF(false); }
     else if (far_cam) { if (repl) RTC_F64_W(true, true); else RTC_F64_W(true, false); }
     else { if (repl) RTC_F64_W(false, true); else RTC_F64_W(false, false); }
 #endif
+#undef RTC_F64_PROF
 #undef RTC_F64_CSG
 #undef RTC_F64_W
 #undef RTC_F64

@@ -6,16 +6,17 @@
 
 namespace rtc {
 
-// CSG: 0 = the scene has no CSG object and no perturbed pattern, 1 = it has, 2 = and some CSG root is evaluated list-free
+// CSG: 0 = the scene has no CSG object and no perturbed pattern, 1 = it has, 2 = and some CSG root is evaluated list-free,
+// 3 = like 0, with instanced meshes (rtc_scene_desc::inst)
 // REPL: the pixels of split parts are traced by 4 or 16 lanes each (never with PROF)
 // WAVES: resident waves per SIMD the register budget is cut for (512 / WAVES registers per lane).  fp64 without CSG is built
 // for 4 (128 registers, 18 - 40 spilled) and for 2 (its ~150 registers, nothing spilled, three waves resident in effect): which
 // is faster depends on the scene -- tree walks want the waves, fp64 pattern arithmetic wants the registers -- and launch()
 // times both for every view.
-#define RTC_WAVES_OF(R, CSG) ((CSG) ? 2 : sizeof(R) == 8 ? RTC_WAVES_F64 : RTC_WAVES_F32)
+#define RTC_WAVES_OF(R, CSG) (((CSG) == 1 || (CSG) == 2) ? 2 : sizeof(R) == 8 ? RTC_WAVES_F64 : RTC_WAVES_F32)
 template <class R, bool PROF, int CSG, bool FAR, bool REPL, int WAVES>
-__global__ __launch_bounds__((CSG > 0) ? RTC_BLOCK_CSG : RTC_BLOCK_PLAIN, WAVES) void trace_kernel(rtc::DScene<R> S, rtc::DCamera<R> cam, rtc::DFrame F, R shade_eps, R shade_eps_rel) {
-    using CNT = rtc::Counters<PROF, (CSG > 0), FAR, (CSG == 2), REPL>;
+__global__ __launch_bounds__((CSG == 1 || CSG == 2) ? RTC_BLOCK_CSG : RTC_BLOCK_PLAIN, WAVES) void trace_kernel(rtc::DScene<R> S, rtc::DCamera<R> cam, rtc::DFrame F, R shade_eps, R shade_eps_rel) {
+    using CNT = rtc::Counters<PROF, (CSG == 1 || CSG == 2), FAR, (CSG == 2), REPL, (CSG == 3)>;
     __shared__ int s_stack[RTC_BVH_STACK * CNT::kBlock];
     int* stack = s_stack + threadIdx.x;
     const int lane = threadIdx.x & 63;

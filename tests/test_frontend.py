@@ -473,3 +473,41 @@ def test_triangle_runs_flatten_like_the_objects():
     mesh.divide(4)                                        # sub-groups are new groups: no runs, same leaves by another route
     assert all(not g.triangle_runs for g in mesh.children)
     assert compile_scene(world).counts["n_tris"] == fast.counts["n_tris"]
+
+
+def test_repeated_meshes_become_instances():
+    """compile_scene(world, instancing=True): the dragons pack loads one OBJ six times -- one object-space mesh, six instances
+    whose leaves keep their depth-first numbers; nothing else about the scene changes; "auto" (the default) keeps the dragons
+    flattened (too few triangles saved to pay for the slower fp64 walk); scenes without repeats are left alone."""
+    cam, world, _ = load_pack("dragons")
+    flat, inst, auto = compile_scene(world, instancing=False), compile_scene(world, instancing=True), compile_scene(world)
+    assert auto.counts == flat.counts
+    C, A = inst.counts, inst.arrays
+    assert (C["n_instances"], C["n_meshes"], C["n_mesh_tris"], C["n_tris"]) == (6, 1, 23490, 0)
+    assert C["n_leaves"] == flat.counts["n_leaves"] and C["n_items"] == flat.counts["n_items"] - 140940 + 6
+    for name in ("leaf_kind", "leaf_xform", "leaf_material", "leaf_minmax", "leaf_closed", "xform", "mat", "light_geom"):
+        np.testing.assert_array_equal(A[name], flat.arrays[name])
+    kinds = (A["item_prim"].view(np.uint32) >> 28)
+    assert (kinds == 9).sum() == 6 and (kinds == 5).sum() == 0
+    for q, (mesh, xrow, leaf0, mat) in enumerate(A["inst"]):
+        assert mesh == 0
+        np.testing.assert_array_equal(A["leaf_tri"][leaf0:leaf0 + 23490], -2 - np.arange(23490))
+        assert (A["leaf_xform"][leaf0:leaf0 + 23490] == xrow).all() and (A["leaf_material"][leaf0:leaf0 + 23490] == mat).all()
+        # the instance's world box = the box of the flattened copy's triangles
+        item = np.nonzero(A["item_prim"].view(np.uint32) == np.uint32((9 << 28) | q))[0][0]
+        rows = flat.arrays["tri_geom"][flat.arrays["leaf_tri"][leaf0:leaf0 + 23490]]
+        pts = np.concatenate([rows[:, 0:3], rows[:, 0:3] + rows[:, 3:6], rows[:, 0:3] + rows[:, 6:9]])
+        np.testing.assert_allclose(A["item_lo"][item], pts.min(axis=0), atol=1e-12)
+        np.testing.assert_allclose(A["item_hi"][item], pts.max(axis=0), atol=1e-12)
+    # object-space rows through an instance's transform = the flattened copy's world-space rows
+    leaf0, xrow = int(A["inst"][2][2]), int(A["inst"][2][1])
+    m = np.vstack([A["xform"][xrow].reshape(3, 4), [0, 0, 0, 1]])
+    a = np.linalg.inv(m)
+    g = A["mesh_geom"]
+    world_rows = flat.arrays["tri_geom"][flat.arrays["leaf_tri"][leaf0:leaf0 + 23490]]
+    np.testing.assert_allclose(g[:, 0:3] @ a[:3, :3].T + a[:3, 3], world_rows[:, 0:3], atol=1e-12)
+    np.testing.assert_allclose(g[:, 3:6] @ a[:3, :3].T, world_rows[:, 3:6], atol=1e-12)
+    assert (g[:, 9] == 0.000001).all()
+    for name in ("teapot", "cover"):
+        cam, world, _ = load_pack(name)
+        assert compile_scene(world, instancing=True).counts["n_instances"] == 0

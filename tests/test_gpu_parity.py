@@ -459,7 +459,7 @@ def test_triangle_bvh_built_on_the_gpu(name, size, stride, oracle_cls):
     if size:
         cam = cam.resized(*size)
     sample = _oracle_sample(_ORACLE_SAMPLES, oracle_cls, (name, cam.hsize, cam.vsize, stride), world, cam, stride)
-    with _ffi.Scene(compile_scene(world), device=0) as sc:
+    with _ffi.Scene(compile_scene(world, instancing=False), device=0) as sc:
         s0, s1 = {}, {}
         a, ia = sc.render(cam, precision="fp64", want_ids=True, stats=s0)
         a32, _ = sc.render(cam, precision="fp32")
@@ -495,7 +495,7 @@ def test_scene_created_with_build_on_device(name, size, stride, oracle_cls):
     if size:
         cam = cam.resized(*size)
     sample = _oracle_sample(_ORACLE_SAMPLES, oracle_cls, (name, cam.hsize, cam.vsize, stride), world, cam, stride)
-    cs = compile_scene(world)
+    cs = compile_scene(world, instancing=False)
     with _ffi.Scene(cs, device=0, build_on_device=True) as sc:
         info = sc.info()
         assert info["bvh_nodes"] > 0 and info["bvh_depth"] <= 31
@@ -511,6 +511,106 @@ def test_scene_created_with_build_on_device(name, size, stride, oracle_cls):
         sc.build_bvh_on_device()
         c, ic = sc.render(cam, precision="fp64", want_ids=True)
         _against_oracle("... rebuilt: %s" % name, sample, cam, c, ic)
+
+
+def test_instanced_dragons_against_the_oracle(oracle_cls):
+    """Instanced meshes (rtc_scene_desc::inst; compile_scene(world, instancing=True)): bounding_boxes.yml loads dragon.obj six
+    times, the mesh is kept once in object space with six instances.  The frame is held to the ORACLE like every other (fp64:
+    every differing pixel classified, none unexplained; fp32 within the gate), hit ids keep the depth-first leaf numbering,
+    the flattened form gives the same frame to rounding and the same ray counts, and the scene takes a third of the memory."""
+    cam, world, _ = load_pack("dragons")
+    cam = cam.resized(480, 192)
+    sample = _oracle_sample(_ORACLE_SAMPLES, oracle_cls, ("dragons", cam.hsize, cam.vsize, 4), world, cam, 4)
+    flat, inst = compile_scene(world, instancing=False), compile_scene(world, instancing=True)
+    assert inst.counts["n_instances"] == 6 and inst.counts["n_meshes"] == 1 and inst.counts["n_mesh_tris"] == 23490 and inst.counts["n_tris"] == 0
+    assert flat.counts["n_instances"] == 0 and flat.counts["n_tris"] == 140940 and flat.counts["n_leaves"] == inst.counts["n_leaves"]
+    with _ffi.Scene(flat, device=0) as sc:
+        s0 = {}
+        a, ia = sc.render(cam, precision="fp64", want_ids=True, stats=s0)
+        bytes_flat = sc.info()["device_bytes_fp64"]
+    with _ffi.Scene(inst, device=0) as sc:
+        s1 = {}
+        b, ib = sc.render(cam, precision="fp64", want_ids=True, stats=s1)
+        b32, ib32 = sc.render(cam, precision="fp32", want_ids=True)
+        assert sc.last_launch()["csg"] == 3                      # the kernel variants that walk instances
+        assert sc.info()["device_bytes_fp64"] < 0.4 * bytes_flat
+        _against_oracle("instanced dragons %dx%d" % (cam.hsize, cam.vsize), sample, cam, b, ib)
+        assert frac_off_by_more_than_one(b32[sample[1], sample[2]], sample[3]) <= 0.001
+        _same_image(a, b, ia, ib)
+        assert s0["rays"] == s1["rays"] and s0["shadow_rays_culled"] == s1["shadow_rays_culled"]
+        for k in range(6):                                       # later frames (launch order, split parts, replicas): the same image
+            c, ic = sc.render(cam, precision="fp64", want_ids=True)
+            np.testing.assert_array_equal(b, c)
+            np.testing.assert_array_equal(ib, ic)
+
+
+def test_instanced_meshes_among_other_things(oracle_cls):
+    """Two meshes, three and two instances, under shear / rotation / non-uniform scale; one instance of glass (the n1 / n2
+    container pass walks instances too), one that casts no shadow, a patterned one (pattern space = the instance's object
+    space); spheres, a plane and loose triangles beside them.  Full frame against the oracle, instanced and flattened."""
+    import io
+    from ray_tracer_challenge_amd import shapes as S
+    from ray_tracer_challenge_amd.canvas import color
+    from ray_tracer_challenge_amd.matrix import rotation_x, rotation_y, scaling, shearing, translation
+    from ray_tracer_challenge_amd.obj_parser import OBJParser, obj_to_group
+    from ray_tracer_challenge_amd.renderer import Camera, PointLight, World, view_transform
+    from ray_tracer_challenge_amd.vector import point, vector
+
+    def ball_obj(n_lat, n_lon, squash):
+        """OBJ text of a tessellated ellipsoid with vertex normals: 2 n_lat n_lon triangles"""
+        lines, idx = [], {}
+        for i in range(n_lat + 1):
+            for j in range(n_lon):
+                th, ph = np.pi * i / n_lat, 2 * np.pi * j / n_lon
+                x, y, z = np.sin(th) * np.cos(ph), np.cos(th) * squash, np.sin(th) * np.sin(ph)
+                idx[(i, j)] = len(idx) + 1
+                lines.append("v %.9f %.9f %.9f" % (x, y, z))
+                lines.append("vn %.9f %.9f %.9f" % (x, y / squash ** 2, z))
+        lines.append("g ball")
+        for i in range(n_lat):
+            for j in range(n_lon):
+                a, b, c, d = idx[(i, j)], idx[(i, (j + 1) % n_lon)], idx[(i + 1, (j + 1) % n_lon)], idx[(i + 1, j)]
+                lines.append("f %d//%d %d//%d %d//%d" % (a, a, b, b, c, c))
+                lines.append("f %d//%d %d//%d %d//%d" % (a, a, c, c, d, d))
+        return "\n".join(lines)
+
+    def mesh(text, material, transform):
+        g = obj_to_group(OBJParser(io.StringIO(text), default_material=material))
+        g.transform = transform
+        return g
+    big, small = ball_obj(24, 24, 0.6), ball_obj(23, 23, 1.3)          # 1152 and 1058 triangles
+    glass = S.Material(color=color(0.1, 0.1, 0.2), diffuse=0.2, transparency=0.9, reflective=0.3, refractive_index=1.4)
+    ghost = S.Material(color=color(0.9, 0.8, 0.1), casts_shadow=False)
+    striped = S.Material(pattern=S.Stripe(color(1, 0, 0), color(1, 1, 1), scaling(0.25, 0.25, 0.25) * rotation_y(0.5)))
+    plain = S.Material(color=color(0.2, 0.7, 0.3), reflective=0.2)
+    things = [
+        S.Plane(S.Material(color=color(0.6, 0.6, 0.6), reflective=0.1), translation(0, -1.5, 0)),
+        mesh(big, plain, translation(-2.2, 0, 0.5) * shearing(0.3, 0, 0, 0, 0, 0.2)),
+        mesh(big, glass, translation(0, 0.1, 0) * rotation_x(0.6) * scaling(1.1, 1.4, 0.9)),
+        mesh(big, striped, translation(2.3, 0.2, 1.0) * rotation_y(1.1)),
+        S.Group(S.Material(), translation(0, 0, 3), [mesh(small, ghost, translation(-1.2, 0.8, 0) * scaling(0.8, 0.8, 0.8)),
+                                                     mesh(small, plain, translation(1.4, 0.6, 0.5) * scaling(0.7, 1.0, 0.7))]),
+        S.Sphere(S.Material(color=color(0.8, 0.2, 0.2)), translation(0, 0.1, 0) * scaling(0.4, 0.4, 0.4)),      # inside the glass mesh
+        S.Triangle(S.Material(color=color(0.3, 0.3, 0.8)), None, point(-3, -1.5, 4), point(3, -1.5, 4), point(0, 3, 4.5)),
+    ]
+    world = World([PointLight(point(-6, 8, -8), color(0.9, 0.9, 0.9)), PointLight(point(5, 3, -6), color(0.3, 0.3, 0.3))], things)
+    cam = Camera(96, 64, 1.0, view_transform(point(0, 1.5, -7), point(0, 0.2, 0), vector(0, 1, 0)))
+    inst, flat = compile_scene(world, instancing=True), compile_scene(world, instancing=False)
+    assert inst.counts["n_instances"] == 5 and inst.counts["n_meshes"] == 2 and inst.counts["n_tris"] == 1
+    px, py = np.meshgrid(np.arange(cam.hsize), np.arange(cam.vsize), indexing="ij")
+    px, py = px.ravel().astype(np.int32), py.ravel().astype(np.int32)
+    orc = oracle_cls(world)
+    want, leaf, _, _ = orc.render_pixels(cam, px, py)
+    frames = {}
+    for label, cs in (("instanced", inst), ("flattened", flat)):
+        with _ffi.Scene(cs, device=0) as sc:
+            rgb, ids = sc.render(cam, precision="fp64", want_ids=True)
+            rgb32, _ = sc.render(cam, precision="fp32")
+            _against_oracle("two meshes, five instances (%s)" % label, (orc, px, py, want, leaf), cam, rgb, ids, allowed=0.004)
+            assert frac_off_by_more_than_one(rgb32[px, py], want) <= 0.002
+            frames[label] = (rgb, ids)
+    assert np.mean(np.any(np.abs(frames["instanced"][0] - frames["flattened"][0]) > 1e-9, axis=2)) <= 0.004
+    assert np.mean(frames["instanced"][1] != frames["flattened"][1]) <= 0.004
 
 
 def _moved_teapot(fn):
