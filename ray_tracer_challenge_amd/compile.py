@@ -330,9 +330,14 @@ class _Compiler(object):
         # ---- repeated meshes: which loader-made runs become instances of one object-space mesh ----
         mesh_of_run, meshes = {}, []                       # run index -> (mesh, instance); meshes: (first mesh row, block)
         if self.instancing and not self.csg_roots and not any(op == OP_PERTURB for op, _ in self.instr):    # (those scenes' kernels carry no instance walk)
-            groups = {}
-            for ri, (leaf0, n, xrow, mat, tri0, block, in_csg) in enumerate(self.runs):
+            groups, by_size = {}, {}
+            for leaf0, n, xrow, mat, tri0, block, in_csg in self.runs:
                 if not in_csg and n >= MIN_INSTANCE_TRIS:
+                    by_size[n] = by_size.get(n, 0) + 1
+            # (hashing the vertex blocks costs milliseconds: not when even equal sizes cannot add up to what "auto" asks for)
+            worth = self.instancing is True or sum(n * (c - 1) for n, c in by_size.items()) >= AUTO_INSTANCE_SAVED_TRIS
+            for ri, (leaf0, n, xrow, mat, tri0, block, in_csg) in enumerate(self.runs if worth else []):
+                if not in_csg and n >= MIN_INSTANCE_TRIS and by_size[n] >= 2:
                     groups.setdefault((n, hashlib.sha1(np.ascontiguousarray(block).tobytes()).digest()), []).append(ri)
             n_inst, row0 = 0, 0
             picked = sorted(groups.items(), key=lambda kv: -kv[0][0] * len(kv[1]))                  # the most triangles saved first
@@ -387,7 +392,6 @@ class _Compiler(object):
                 continue
             leaf_tri[leaf0:leaf0 + n] = np.arange(tri0, tri0 + n)
             txf[tri0:tri0 + n], tri_leaf[tri0:tri0 + n] = xrow, np.arange(leaf0, leaf0 + n)
-            rows[tri0:tri0 + n] = block
             if not in_csg:
                 run_items.append(np.stack([np.full(n, K_TRIANGLE, np.int64), np.arange(leaf0, leaf0 + n, dtype=np.int64)], axis=1))
         leaf_noshadow = (mat_shadow[leaf_material] == 0) if n_leaves else np.zeros(0, bool)
@@ -407,28 +411,37 @@ class _Compiler(object):
                     except ValueError:                                                  # mixed 3- and 4-component tuples
                         block = np.array([[np.asarray(v, f64)[:3] for v in self.tri_rows[i]] for i in pick], f64)
                     rows[single[pick], :3 * k] = block[:, :, :3].reshape(pick.size, 3 * k)
-            for xi in np.unique(txf):
-                sel = np.nonzero(txf == xi)[0]
+            def to_world(r, fl, xi, where):
+                """rows r (n, 18: p1 p2 p3 n1 n2 n3, object space) under transform row xi -> tri_geom / tri_norm / boxes at `where`
+                (a slice for a loader-made run, an index array for triangles that came one by one)"""
                 m = xf[xi]
                 a = np.linalg.inv(m)                       # object -> world
                 a3, t3, m3 = a[:3, :3], a[:3, 3], m[:3, :3]
-                r = rows[sel]
                 p = [r[:, 3 * k:3 * k + 3] @ a3.T + t3 for k in range(3)]
-                e1o, e2o = r[:, 3:6] - r[:, 0:3], r[:, 6:9] - r[:, 0:3]
-                fn = np.cross(e2o, e1o)                    # shapes.py:807
-                with np.errstate(invalid="ignore", divide="ignore"):
-                    fn = fn * (1.0 / np.sqrt(np.sum(fn * fn, axis=1, keepdims=True)))
-                fl = flat[sel]
-                normals = [np.where(fl[:, None], fn, r[:, 9 + 3 * k:12 + 3 * k]) @ m3 for k in range(3)]  # M^T n
-                g = tri_geom[sel]
+                if fl is None:                             # a loader's run: smooth triangles, the normals are in the rows
+                    normals = [r[:, 9 + 3 * k:12 + 3 * k] @ m3 for k in range(3)]                              # M^T n
+                else:
+                    e1o, e2o = r[:, 3:6] - r[:, 0:3], r[:, 6:9] - r[:, 0:3]
+                    fn = np.cross(e2o, e1o)                # shapes.py:807
+                    with np.errstate(invalid="ignore", divide="ignore"):
+                        fn = fn * (1.0 / np.sqrt(np.sum(fn * fn, axis=1, keepdims=True)))
+                    normals = [np.where(fl[:, None], fn, r[:, 9 + 3 * k:12 + 3 * k]) @ m3 for k in range(3)]
+                g = np.empty((len(r), 12))
                 g[:, 0:3], g[:, 3:6], g[:, 6:9] = p[0], p[1] - p[0], p[2] - p[0]
-                g[:, 9] = EPSILON * abs(np.linalg.det(a3))
-                tri_geom[sel] = g
-                nn = tri_norm[sel]
+                g[:, 9], g[:, 10:12] = EPSILON * abs(np.linalg.det(a3)), 0.0
+                tri_geom[where] = g
+                nn = np.zeros((len(r), 12))
                 nn[:, 0:3], nn[:, 3:6], nn[:, 6:9] = normals
-                tri_norm[sel] = nn
-                pts = np.stack(p, axis=0)
-                tri_lo[sel], tri_hi[sel] = pts.min(axis=0), pts.max(axis=0)
+                tri_norm[where] = nn
+                tri_lo[where] = np.minimum(np.minimum(p[0], p[1]), p[2])
+                tri_hi[where] = np.maximum(np.maximum(p[0], p[1]), p[2])
+            for ri, (leaf0, n, xrow, mat, tri0, block, in_csg) in enumerate(self.runs):
+                if ri not in mesh_of_run:
+                    to_world(block, None, xrow, slice(tri0, tri0 + n))
+            if single.size:
+                for xi in np.unique(txf[single]):
+                    sel = single[txf[single] == xi]
+                    to_world(rows[sel], flat[sel], xi, sel)
         # world AABB per leaf as arrays (NaN = no finite box): analytic leaves from the walk, triangles in bulk
         leaf_lo = np.full((n_leaves, 3), np.nan)
         leaf_hi = np.full((n_leaves, 3), np.nan)

@@ -2,6 +2,7 @@
 // Built by hipcc for gfx950 into librtc_hip.so together with rtc_trace_f64.hip (the fp64 trace kernels without CSG).
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -565,7 +566,20 @@ float g_split16 = [] { const char* e = getenv("RTC_SPLIT16"); return e ? (float)
 
 int rebuild_triangle_bvh_device(rtc_scene* sc, bool again = false);
 
+// development (RTC_BVH_INFO=1): where rtc_scene_create's time goes
+struct CreateClock {
+    const bool on = getenv("RTC_BVH_INFO") != nullptr;
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    void tick(const char* what) {
+        if (!on) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[rtc] create: %-28s %7.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t).count());
+        t = now;
+    }
+};
+
 int create_impl(const rtc_scene_desc& d, rtc_scene* sc) {
+    CreateClock clk;
     {
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, sc->device));
@@ -606,6 +620,7 @@ int create_impl(const rtc_scene_desc& d, rtc_scene* sc) {
     sc->bvh_nodes = bvh.n_nodes() + tbvh.n_nodes(); sc->bvh_depth = std::max(bvh.depth, tbvh.depth);
     sc->bvh_max_leaf = std::max(bvh.max_leaf, tbvh.max_leaf);
     sc->obj_depth = bvh.depth; sc->obj_max_leaf = bvh.max_leaf;
+    clk.tick("host trees");
     std::vector<int32_t> prims(oprim.size());
     for (size_t i = 0; i < oprim.size(); i++) prims[i] = oprim[bvh.order[i]];
     // triangles in BVH leaf order: geometry rows + (leaf id | noshadow << 31)
@@ -693,6 +708,7 @@ int create_impl(const rtc_scene_desc& d, rtc_scene* sc) {
     UP(light_type, d.light_type, d.n_lights);
     UP(light_steps, d.light_steps, 3 * (size_t)d.n_lights);
 #undef UP
+    clk.tick("index arrays up");
     S.n_leaves = d.n_leaves;
     S.n_bvh_nodes = bvh.n_nodes();
     S.n_tnodes = tbvh.n_nodes();
@@ -754,6 +770,7 @@ int create_impl(const rtc_scene_desc& d, rtc_scene* sc) {
         std::vector<float> g32 = cast_vec<float>(tb_geom.data(), tb_geom.size());
         if (int rc = sc->tbvh_mem.upload(g32.data(), g32.size(), &sc->d32.tb_geom)) return rc;
     }
+    clk.tick("nodes and rows up");
     // ---- instanced meshes: one tree and one set of rows per mesh, in its object space ----
     if (d.n_instances > 0) {
         std::vector<rtc::BvhNode4> mnodes;
@@ -833,8 +850,11 @@ int create_impl(const rtc_scene_desc& d, rtc_scene* sc) {
         S.n_inst = d.n_instances;
         F.n_inst = S.n_inst; F.mnodes4 = S.mnodes4; F.mb_leaf = S.mb_leaf; F.inst = S.inst; F.inst_box = S.inst_box; F.inst_far = S.inst_far;
     }
+    clk.tick("instanced meshes");
     if (int rc = upload_real<double>(d, quadric_minmax, sc->mem64, sc->d64)) return rc;
+    clk.tick("fp64 arrays up");
     if (int rc = upload_real<float>(d, quadric_minmax, sc->mem32, sc->d32)) return rc;
+    clk.tick("fp32 arrays cast and up");
     if ((sc->d64.n_bvh_nodes > 0 && (!sc->d64.nodes || !sc->d64.bvh_prims || !sc->d32.nodes)) ||
         (sc->d64.n_tnodes > 0 && (!sc->d64.tnodes || !sc->d64.tnodes4 || !sc->d32.tnodes4 || !sc->d64.tb_geom || !sc->d64.tb_leaf || !sc->d32.tnodes || !sc->d32.tb_geom)))
         return fail(RTC_ERR_HIP, "internal: BVH arrays missing on the device");
@@ -847,7 +867,7 @@ int create_impl(const rtc_scene_desc& d, rtc_scene* sc) {
         sc->light_cells += d.light_type[i] == 1 ? (long long)d.light_steps[3 * i] * d.light_steps[3 * i + 1] : 1;
         if (d.light_type[i] == 1 && d.light_steps[3 * i + 2]) sc->has_jitter = true;
     }
-    if (device_build) return rebuild_triangle_bvh_device(sc, false);
+    if (device_build) { const int rc = rebuild_triangle_bvh_device(sc, false); clk.tick("tree built on the device"); return rc; }
     return 0;
 }
 
