@@ -1,7 +1,7 @@
 // rtc_device.hpp -- device side of the MI355X trace loop (gfx950, wave64).
 //
 // Everything the reference does per ray in Python lives here as inlined device functions,
-// templated on the arithmetic type R (double = the reference's fp64, float = throughput mode).
+// templated on the arithmetic type R (double = the reference's fp64, float = the fp32 mode: half the registers and bytes, gated at 1/255 against fp64).
 // Citations are reference file:line.  Differences from the reference's *structure* (none of
 // them change a hit list):
 //   * one collapsed world->object 3x4 per leaf instead of an inverse per tree level;
