@@ -347,7 +347,7 @@ def random_mesh_world(seed):
     return cam, World(lights, objs), rng
 
 
-@pytest.mark.parametrize("seed", range(8))
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("RTC_FUZZ_MESH_SEEDS", "8"))))
 def test_random_mesh_world(seed, oracle_cls):
     """Triangle-BVH route: a tessellated mesh (flat or smooth, possibly glass or mirror) among a few primitives -- host-built
     tree against the oracle, then the GPU-built tree and a refit of it against the host-built one, then a random subset of
