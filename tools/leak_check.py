@@ -28,5 +28,20 @@ for it in range(n):
         marks.append((it, free() / 2**20, _ffi._pinned.total / 2**20))
         print("iteration %d: device free %.1f MiB, pinned pool %.1f MiB" % marks[-1], flush=True)
 assert abs(marks[-1][1] - marks[1][1]) < 64, "device memory drifted"
+# the dragons: instanced meshes, and the flattened form with its tree built on the GPU at creation (RTC_BUILD_ON_DEVICE)
+cam, world, _ = load_world(os.path.join(ROOT, "scenes", "dragons.npz"))
+cam = cam.resized(480, 192)
+forms = [(compile_scene(world, instancing=True), False), (compile_scene(world, instancing=False), True)]
+marks = []
+for it in range(max(n // 8, 4)):
+    for cs2, on_device in forms:
+        with _ffi.Scene(cs2, build_on_device=on_device) as sc:
+            sc.render(cam, precision="fp64", want_ids=True)
+            sc.render(cam, precision="fp32")
+            sc.render_ppm(cam)
+    torch.cuda.synchronize()
+    marks.append((it, free() / 2**20, _ffi._pinned.total / 2**20))
+    print("dragons iteration %d: device free %.1f MiB, pinned pool %.1f MiB" % marks[-1], flush=True)
+assert abs(marks[-1][1] - marks[1][1]) < 64, "device memory drifted (instanced / built on device)"
 assert marks[-1][2] <= 1024
 print("no growth")
