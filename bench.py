@@ -24,7 +24,7 @@ K = 20 loop lasts 16 ms: too short for clocks to settle or for anybody outside t
 quotes the MEDIAN repetition and gives the spread.  Every launch sits between two HIP events on its own stream, so
 `roofline.kernel_ms` is the average launch duration inside the very loop `ms_per_step` comes from.
 
-The headline value is measured in fp64, the reference's arithmetic; the fp32 throughput mode is
+The headline value is measured in fp64, the reference's arithmetic; the fp32 mode (half the registers and bytes) is
 timed right after it and reported beside it (`fp32`), never as `value`.
 """
 import argparse
