@@ -134,20 +134,32 @@ __global__ void ploc_init_kernel(int n_leaves, int n_items, const uint32_t* sort
     for (int a = 0; a < 6; a++) cbox[6 * (size_t)j + a] = b[a];
     cluster[j] = j;
 }
-// nearest neighbour of every cluster within `radius` places (smallest area of the union; ties to the lower place, so that
-// "i and j choose each other" is well defined)
+// nearest neighbour of every cluster within `radius` places: smallest area of the union.  Equal areas go to the pair with the
+// smaller hash of its two places -- symmetric in i and j, so the pair that is smallest for both of its members chooses itself
+// from both sides.  (Ties to the lower place, as this first was, make a chain i -> i-1 -> i-2 ... out of equal boxes -- three
+// thousand copies of one triangle merged ONE pair per iteration and ran into the iteration limit, tools/builder_stress.py.)
+__device__ __forceinline__ uint32_t ploc_pair_key(int a, int b) {
+    uint32_t lo = (uint32_t)(a < b ? a : b), hi = (uint32_t)(a < b ? b : a);
+    uint32_t h = lo * 0x9E3779B1u ^ (hi + 0x7F4A7C15u) * 0x85EBCA6Bu;
+    h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12;
+    return h;
+}
 __global__ void ploc_nearest_kernel(const PlocState* st, int radius, const int32_t* cluster, const float* cbox, int32_t* nearest) {
     const int n = st->n;
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (n <= 1 || i >= n) return;
     float mine[6];
     for (int a = 0; a < 6; a++) mine[a] = cbox[6 * (size_t)cluster[i] + a];
-    float best = 3.0e38f; int at = -1;
+    float best = 3.0e38f; int at = -1; uint32_t best_key = 0xFFFFFFFFu;
     const int lo = i - radius < 0 ? 0 : i - radius, hi = i + radius >= n ? n - 1 : i + radius;
     for (int j = lo; j <= hi; j++) {
         if (j == i) continue;
         const float area = ploc_area(mine, cbox + 6 * (size_t)cluster[j]);
-        if (area < best) { best = area; at = j; }
+        if (area < best) { best = area; at = j; best_key = ploc_pair_key(i, j); }
+        else if (area == best && at >= 0) {
+            const uint32_t key = ploc_pair_key(i, j);
+            if (key < best_key) { at = j; best_key = key; }
+        }
     }
     nearest[i] = at;
 }
