@@ -147,7 +147,9 @@ typedef struct {
     /* How rtc_scene_create builds the triangle BVH.  0: binned SAH on the host -- the best tree, tens of milliseconds for 10^5
      * triangles: for scenes that are rendered many times.  RTC_BUILD_ON_DEVICE: on the GPU from the uploaded rows (Morton
      * order + parallel locally-ordered clustering, ~2 ms for 1.4 10^5 triangles; frames ~1.1 x the SAH tree's): for scenes
-     * rendered once, the reference's own use (main.py:305-354: one frame per scene). */
+     * rendered once, the reference's own use (main.py:305-354: one frame per scene).  A request, not a different scene: meshes
+     * under 16 384 triangles get the host's build anyway (it is quicker than the GPU build's fixed costs), and so does a mesh whose
+     * GPU-built tree comes out deeper than the traversal stack (seen at 3.2 10^7 triangles; 8 10^6 fit). */
     int32_t build_flags;
 } rtc_scene_desc;
 #define RTC_BUILD_ON_DEVICE 1

@@ -1399,21 +1399,31 @@ int rtc_scene_create(const rtc_scene_desc* desc, int device, rtc_scene** out) {
     if (n <= 0) return fail(RTC_ERR_NO_DEVICE, "no GPU visible to HIP");
     if (device < 0 || device >= n) return fail(RTC_ERR_NO_DEVICE, "device %d out of range (%d visible)", device, n);
     HIP_TRY(hipSetDevice(device));
-    rtc_scene* sc = nullptr;
-    int rc = 0;
-    try {                                           // the BVH build and the staging copies allocate host memory
-        sc = new rtc_scene();
-        sc->device = device;
-        sc->n_leaves = desc->n_leaves;
-        rc = create_impl(*desc, sc);
-    } catch (const std::bad_alloc&) {
-        rc = fail(RTC_ERR_NOMEM, "out of host memory while building the scene");
-    } catch (const std::exception& e) {
-        rc = fail(RTC_ERR_INVALID, "scene build failed: %s", e.what());
+    rtc_scene_desc d = *desc;
+    for (int attempt = 0; ; attempt++) {
+        rtc_scene* sc = nullptr;
+        int rc = 0;
+        try {                                           // the BVH build and the staging copies allocate host memory
+            sc = new rtc_scene();
+            sc->device = device;
+            sc->n_leaves = d.n_leaves;
+            rc = create_impl(d, sc);
+        } catch (const std::bad_alloc&) {
+            rc = fail(RTC_ERR_NOMEM, "out of host memory while building the scene");
+        } catch (const std::exception& e) {
+            rc = fail(RTC_ERR_INVALID, "scene build failed: %s", e.what());
+        }
+        if (!rc) { *out = sc; return 0; }
+        if (sc) rtc_scene_destroy(sc);
+        // RTC_BUILD_ON_DEVICE is a request for speed, not a different scene: a mesh whose GPU-built tree comes out deeper than
+        // the traversal stack (tens of millions of triangles) gets the host's build, which is made to fit (build_bvh's depth budget)
+        if (rc == RTC_ERR_LIMIT && attempt == 0 && (d.build_flags & RTC_BUILD_ON_DEVICE)) {
+            if (getenv("RTC_BVH_INFO")) fprintf(stderr, "[rtc] create: %s -- building the tree on the host instead\n", rtc_last_error());
+            d.build_flags &= ~RTC_BUILD_ON_DEVICE;
+            continue;
+        }
+        return rc;
     }
-    if (rc) { if (sc) rtc_scene_destroy(sc); return rc; }
-    *out = sc;
-    return 0;
 }
 
 void rtc_scene_destroy(rtc_scene* scene) {
