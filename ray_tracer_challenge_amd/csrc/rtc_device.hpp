@@ -576,6 +576,20 @@ struct PrimCode {
 
 // What the box tests of a walk need of the ray: reciprocal direction, -origin / direction, the near bound (fp32, see traverse_bvh)
 struct SlabRay { float ix, iy, iz, ox, oy, oz, tlo32; };
+// The ray's share of that, made once per ray and used by every walk of it (object tree, triangle tree, the box around a flat
+// list): slab distance (b - o) / d as one fused multiply-add b * (1/d) + (-o/d); a direction component of 0 gets a huge finite
+// reciprocal instead of inf, so that no 0 * inf appears (the sign of b - o then decides, as it should, and the boxes' outward
+// padding covers an origin that sits on the slab plane).  (Each walk used to make its own: three sets of reciprocals a ray.)
+struct RayInv { float ix, iy, iz, ox, oy, oz; };
+template <class R> __device__ __forceinline__ RayInv ray_inv(const Ray<R>& ray) {
+    RayInv q;
+    q.ix = 1.0f / (float)ray.d.x; q.iy = 1.0f / (float)ray.d.y; q.iz = 1.0f / (float)ray.d.z;
+    if (!(fabsf(q.ix) <= 1e30f)) q.ix = copysignf(1e30f, (float)ray.d.x);
+    if (!(fabsf(q.iy) <= 1e30f)) q.iy = copysignf(1e30f, (float)ray.d.y);
+    if (!(fabsf(q.iz) <= 1e30f)) q.iz = copysignf(1e30f, (float)ray.d.z);
+    q.ox = -(float)ray.o.x * q.ix; q.oy = -(float)ray.o.y * q.iy; q.oz = -(float)ray.o.z * q.iz;
+    return q;
+}
 // entry and exit distance of the ray in one box (lo xyz, hi xyz), with the outward slack of traverse_bvh
 __device__ __forceinline__ void slab_test(float lx, float ly, float lz, float hx, float hy, float hz, const SlabRay& s, float& n, float& f) {
     const float x0 = fmaf(lx, s.ix, s.ox), x1 = fmaf(hx, s.ix, s.ox);
@@ -686,20 +700,15 @@ template <int STRIDE, bool UNORDERED> __device__ __forceinline__ int bvh4_visit(
 // The OBJECT BVH (binary; leaves hold prim codes -> vis.prim); the triangle BVH is walked four-wide, traverse_bvh4.
 // Returns true if the visitor stopped it.
 template <class R, class V>
-__device__ __forceinline__ bool traverse_bvh(const DScene<R>& S, const Ray<R>& ray, R tlo, V& vis, int* stack /* LDS, stride = threads per workgroup */) {
+__device__ __forceinline__ bool traverse_bvh(const DScene<R>& S, const Ray<R>& ray, const RayInv& ri, R tlo, V& vis, int* stack /* LDS, stride = threads per workgroup */) {
     constexpr int kStride = std::remove_reference_t<decltype(vis.cnt)>::kBlock;
     const BvhNode* __restrict__ nodes = S.nodes;
     // Box tests run in fp32 whatever R is: the boxes are padded outward by 2e-5 (relative, >= 2e-5
     // absolute) on the host, which covers rounding the ray to fp32, and the slab distances get a
     // 1e-5 relative slack before every comparison -- the test can only accept MORE than an exact
     // one would, never less, so no leaf the leaf test would accept is culled.
-    // slab distance (b - o) / d as one fused multiply-add b * (1/d) + (-o/d); a direction component of 0
-    // gets a huge finite reciprocal instead of inf, so that no 0 * inf appears (the sign of b - o then
-    // decides, as it should, and the outward padding covers an origin that sits on the slab plane)
-    float ix = 1.0f / (float)ray.d.x, iy = 1.0f / (float)ray.d.y, iz = 1.0f / (float)ray.d.z;
-    if (!(fabsf(ix) <= 1e30f)) ix = copysignf(1e30f, (float)ray.d.x);
-    if (!(fabsf(iy) <= 1e30f)) iy = copysignf(1e30f, (float)ray.d.y);
-    if (!(fabsf(iz) <= 1e30f)) iz = copysignf(1e30f, (float)ray.d.z);
+    // (the reciprocal direction and -origin / direction: ray_inv)
+    const float ix = ri.ix, iy = ri.iy, iz = ri.iz;
     // The fp32 slab arithmetic rounds relative to the ray's ORIGIN.  Boxes are padded (pad_boxes) by at least 8e-7 of
     // the largest coordinate in the scene, which covers rounding an origin of up to twice that size; a ray that starts
     // farther out (a camera thousands of units from a small mesh) would see the boxes displaced by more than their
@@ -708,7 +717,7 @@ __device__ __forceinline__ bool traverse_bvh(const DScene<R>& S, const Ray<R>& r
     // entry point, not exact, so it is found in fp32.  Only the kernel variants for far cameras (Counters::kFar) carry this:
     // every other ray of a frame starts on a surface of the scene.  base = 0 changes nothing.
     float base32 = 0.0f, lim_pad = 0.0f;
-    float ox = -(float)ray.o.x * ix, oy = -(float)ray.o.y * iy, oz = -(float)ray.o.z * iz;
+    float ox = ri.ox, oy = ri.oy, oz = ri.oz;
     float tlo32 = (float)tlo;
     if (V::Cnt::kFar && fmaxf(fmaxf(fabsf((float)ray.o.x), fabsf((float)ray.o.y)), fabsf((float)ray.o.z)) > S.far_origin) {
         const float* rb = S.obox;
@@ -779,16 +788,13 @@ __device__ __forceinline__ bool traverse_bvh(const DScene<R>& S, const Ray<R>& r
 // INST: the tree of an instanced mesh (`ray` already in its object space; triangles go to vis.tri<true>): nodes, root and the
 // box / far_origin for re-basing are the instance's.
 template <class R, class V, bool INST = false>
-__device__ __forceinline__ bool traverse_bvh4(const DScene<R>& S, const Ray<R>& ray, R tlo, V& vis, int* stack /* LDS, stride = threads per workgroup */,
+__device__ __forceinline__ bool traverse_bvh4(const DScene<R>& S, const Ray<R>& ray, const RayInv& ri, R tlo, V& vis, int* stack /* LDS, stride = threads per workgroup */,
                                               int inst = 0, int root = 0) {
     constexpr int kStride = std::remove_reference_t<decltype(vis.cnt)>::kBlock;
     const BvhNode4* __restrict__ nodes = INST ? S.mnodes4 : S.tnodes4;
-    float ix = 1.0f / (float)ray.d.x, iy = 1.0f / (float)ray.d.y, iz = 1.0f / (float)ray.d.z;
-    if (!(fabsf(ix) <= 1e30f)) ix = copysignf(1e30f, (float)ray.d.x);
-    if (!(fabsf(iy) <= 1e30f)) iy = copysignf(1e30f, (float)ray.d.y);
-    if (!(fabsf(iz) <= 1e30f)) iz = copysignf(1e30f, (float)ray.d.z);
+    const float ix = ri.ix, iy = ri.iy, iz = ri.iz;
     float base32 = 0.0f, lim_pad = 0.0f;
-    float ox = -(float)ray.o.x * ix, oy = -(float)ray.o.y * iy, oz = -(float)ray.o.z * iz;
+    float ox = ri.ox, oy = ri.oy, oz = ri.oz;
     float tlo32 = (float)tlo;
     if (V::Cnt::kFar && fmaxf(fmaxf(fabsf((float)ray.o.x), fabsf((float)ray.o.y)), fabsf((float)ray.o.z)) > (INST ? S.inst_far[inst] : S.far_origin)) {      // see traverse_bvh
         const float* rb = INST ? S.inst_box + 6 * inst : S.tbox;
@@ -861,7 +867,7 @@ __device__ __forceinline__ bool traverse_bvh4(const DScene<R>& S, const Ray<R>& 
 
 // the whole scene: unbounded prims, then the object BVH, then the triangle BVH (objects first, so
 // that the mesh walk starts with the tightest bound the cheap part can give)
-template <class R, class V> __device__ __forceinline__ void traverse_objects(const DScene<R>& S, const Ray<R>& ray, R tlo, V& vis, int* stack) {
+template <class R, class V> __device__ __forceinline__ void traverse_objects(const DScene<R>& S, const Ray<R>& ray, const RayInv& ri, R tlo, V& vis, int* stack) {
     for (int i = 0; i < S.n_unbounded; i++)
         if (vis.prim(S.unbounded_prims[i])) return;
     if (S.n_flat_prims > 0) {
@@ -871,14 +877,11 @@ template <class R, class V> __device__ __forceinline__ void traverse_objects(con
         // gives all of it back -- the shadow rays of that scene pass through the boxes anyway.  A single object keeps
         // its BVH: there the root's box test spares the background pixels their fp64 leaf test.)
         if (V::kFlatRootBox) {   // one box around all of them (the tree's own): the same conservative fp32 slab test as traverse_bvh's
-            float ix = 1.0f / (float)ray.d.x, iy = 1.0f / (float)ray.d.y, iz = 1.0f / (float)ray.d.z;
-            if (!(fabsf(ix) <= 1e30f)) ix = copysignf(1e30f, (float)ray.d.x);
-            if (!(fabsf(iy) <= 1e30f)) iy = copysignf(1e30f, (float)ray.d.y);
-            if (!(fabsf(iz) <= 1e30f)) iz = copysignf(1e30f, (float)ray.d.z);
+            const float ix = ri.ix, iy = ri.iy, iz = ri.iz;
             const float* pb = S.obox;
             const bool far_away = V::Cnt::kFar && fmaxf(fmaxf(fabsf((float)ray.o.x), fabsf((float)ray.o.y)), fabsf((float)ray.o.z)) > S.far_origin;
             if (!far_away) {     // (a ray from farther out is not culled here: its leaf tests, in R, decide)
-                const float ox = -(float)ray.o.x * ix, oy = -(float)ray.o.y * iy, oz = -(float)ray.o.z * iz;
+                const float ox = ri.ox, oy = ri.oy, oz = ri.oz;
                 float x0 = fmaf(pb[0], ix, ox), x1 = fmaf(pb[3], ix, ox);
                 float y0 = fmaf(pb[1], iy, oy), y1 = fmaf(pb[4], iy, oy);
                 float z0 = fmaf(pb[2], iz, oz), z1 = fmaf(pb[5], iz, oz);
@@ -894,10 +897,10 @@ template <class R, class V> __device__ __forceinline__ void traverse_objects(con
             if (vis.prim(S.bvh_prims[i])) return;
         return;
     }
-    if (S.n_bvh_nodes > 0) traverse_bvh<R, V>(S, ray, tlo, vis, stack);
+    if (S.n_bvh_nodes > 0) traverse_bvh<R, V>(S, ray, ri, tlo, vis, stack);
 }
-template <class R, class V> __device__ __forceinline__ void traverse_tris(const DScene<R>& S, const Ray<R>& ray, R tlo, V& vis, int* stack) {
-    if (S.n_tnodes > 0) traverse_bvh4<R, V>(S, ray, tlo, vis, stack);
+template <class R, class V> __device__ __forceinline__ void traverse_tris(const DScene<R>& S, const Ray<R>& ray, const RayInv& ri, R tlo, V& vis, int* stack) {
+    if (S.n_tnodes > 0) traverse_bvh4<R, V>(S, ray, ri, tlo, vis, stack);
 }
 // Instances of meshes are prims of the object BVH: the visitors do not walk a mesh where they meet its box (the outer walk's
 // state would stay live through the inner one) but note the instance -- a byte each in one 64-bit word, in the order met,
@@ -909,8 +912,9 @@ struct PendingInstances {
     __device__ __forceinline__ void add(int idx) { if (n < RTC_MAX_INSTANCES) { list |= (unsigned long long)(idx + 1) << (8 * n); n++; } }
 };
 template <class R, class V> __device__ __forceinline__ void traverse(const DScene<R>& S, const Ray<R>& ray, R tlo, V& vis, int* stack) {
-    traverse_objects(S, ray, tlo, vis, stack);
-    if (!vis.done()) traverse_tris(S, ray, tlo, vis, stack);
+    const RayInv ri = ray_inv(ray);
+    traverse_objects(S, ray, ri, tlo, vis, stack);
+    if (!vis.done()) traverse_tris(S, ray, ri, tlo, vis, stack);
     if (V::Cnt::kInst) {
         unsigned long long list = vis.pending.list;
         vis.pending.clear();
@@ -921,7 +925,7 @@ template <class R, class V> __device__ __forceinline__ void traverse(const DScen
             const R* m = S.xform + 12 * (size_t)I[1];
             vis.oray.o = xpoint(m, ray.o); vis.oray.d = xvector(m, ray.d);
             vis.inst_leaf0 = I[2];
-            traverse_bvh4<R, V, true>(S, vis.oray, tlo, vis, stack, inst, I[0]);
+            traverse_bvh4<R, V, true>(S, vis.oray, ray_inv(vis.oray), tlo, vis, stack, inst, I[0]);
         }
     }
 }
