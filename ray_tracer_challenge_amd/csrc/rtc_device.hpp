@@ -699,7 +699,8 @@ template <int STRIDE, bool UNORDERED> __device__ __forceinline__ int bvh4_visit(
 // Boxes are visited when their slab interval overlaps (tlo, limit()).
 // The OBJECT BVH (binary; leaves hold prim codes -> vis.prim); the triangle BVH is walked four-wide, traverse_bvh4.
 // Returns true if the visitor stopped it.
-template <class R, class V>
+// FARW: this walk re-bases rays that start far outside the tree's box (see below)
+template <class R, class V, bool FARW>
 __device__ __forceinline__ bool traverse_bvh(const DScene<R>& S, const Ray<R>& ray, const RayInv& ri, R tlo, V& vis, int* stack /* LDS, stride = threads per workgroup */) {
     constexpr int kStride = std::remove_reference_t<decltype(vis.cnt)>::kBlock;
     const BvhNode* __restrict__ nodes = S.nodes;
@@ -719,7 +720,7 @@ __device__ __forceinline__ bool traverse_bvh(const DScene<R>& S, const Ray<R>& r
     float base32 = 0.0f, lim_pad = 0.0f;
     float ox = ri.ox, oy = ri.oy, oz = ri.oz;
     float tlo32 = (float)tlo;
-    if (V::Cnt::kFar && fmaxf(fmaxf(fabsf((float)ray.o.x), fabsf((float)ray.o.y)), fabsf((float)ray.o.z)) > S.far_origin) {
+    if (FARW && fmaxf(fmaxf(fabsf((float)ray.o.x), fabsf((float)ray.o.y)), fabsf((float)ray.o.z)) > S.far_origin) {
         const float* rb = S.obox;
         const float px = (float)ray.o.x, py = (float)ray.o.y, pz = (float)ray.o.z;
         const float x0 = (rb[0] - px) * ix, x1 = (rb[3] - px) * ix, y0 = (rb[1] - py) * iy, y1 = (rb[4] - py) * iy, z0 = (rb[2] - pz) * iz, z1 = (rb[5] - pz) * iz;
@@ -744,9 +745,9 @@ __device__ __forceinline__ bool traverse_bvh(const DScene<R>& S, const Ray<R>& r
             // every lane of the wave at the same node (the top of the tree, for the rays of one pixel block): the record
             // comes through the scalar unit (one 64-byte scalar load) and leaves the vector memory pipe alone
             float lim = (float)vis.limit();
-            if (V::Cnt::kFar) lim -= base32;                    // (float)limit is off by 6e-8 |limit| <= 6e-8 (|base| + |lim|): lim_pad + the relative slack
+            if (FARW) lim -= base32;                    // (float)limit is off by 6e-8 |limit| <= 6e-8 (|base| + |lim|): lim_pad + the relative slack
             lim += fabsf(lim) * 1e-6f;
-            if (V::Cnt::kFar) lim += lim_pad;
+            if (FARW) lim += lim_pad;
             const SlabRay sr = {ix, iy, iz, ox, oy, oz, tlo32};
             int next;
             NodeRec2 r;
@@ -787,7 +788,7 @@ __device__ __forceinline__ bool traverse_bvh(const DScene<R>& S, const Ray<R>& r
 // distance by then -- the visitor's own comparison decides, as in the binary walk).
 // INST: the tree of an instanced mesh (`ray` already in its object space; triangles go to vis.tri<true>): nodes, root and the
 // box / far_origin for re-basing are the instance's.
-template <class R, class V, bool INST = false>
+template <class R, class V, bool INST = false, bool FARW = V::Cnt::kFar>
 __device__ __forceinline__ bool traverse_bvh4(const DScene<R>& S, const Ray<R>& ray, const RayInv& ri, R tlo, V& vis, int* stack /* LDS, stride = threads per workgroup */,
                                               int inst = 0, int root = 0) {
     constexpr int kStride = std::remove_reference_t<decltype(vis.cnt)>::kBlock;
@@ -796,7 +797,7 @@ __device__ __forceinline__ bool traverse_bvh4(const DScene<R>& S, const Ray<R>& 
     float base32 = 0.0f, lim_pad = 0.0f;
     float ox = ri.ox, oy = ri.oy, oz = ri.oz;
     float tlo32 = (float)tlo;
-    if (V::Cnt::kFar && fmaxf(fmaxf(fabsf((float)ray.o.x), fabsf((float)ray.o.y)), fabsf((float)ray.o.z)) > (INST ? S.inst_far[inst] : S.far_origin)) {      // see traverse_bvh
+    if (FARW && fmaxf(fmaxf(fabsf((float)ray.o.x), fabsf((float)ray.o.y)), fabsf((float)ray.o.z)) > (INST ? S.inst_far[inst] : S.far_origin)) {      // see traverse_bvh
         const float* rb = INST ? S.inst_box + 6 * inst : S.tbox;
         const float px = (float)ray.o.x, py = (float)ray.o.y, pz = (float)ray.o.z;
         const float x0 = (rb[0] - px) * ix, x1 = (rb[3] - px) * ix, y0 = (rb[1] - py) * iy, y1 = (rb[4] - py) * iy, z0 = (rb[2] - pz) * iz, z1 = (rb[5] - pz) * iz;
@@ -821,9 +822,9 @@ __device__ __forceinline__ bool traverse_bvh4(const DScene<R>& S, const Ray<R>& 
             if (__builtin_amdgcn_ballot_w64(node != __builtin_amdgcn_readfirstlane(node)) == 0ull) vis.cnt.work(W_CONTAINER);
 #endif
             float lim = (float)vis.limit();
-            if (V::Cnt::kFar) lim -= base32;
+            if (FARW) lim -= base32;
             lim += fabsf(lim) * 1e-6f;
-            if (V::Cnt::kFar) lim += lim_pad;
+            if (FARW) lim += lim_pad;
             const SlabRay sr = {ix, iy, iz, ox, oy, oz, tlo32};
             constexpr bool kAnyOrder = !RTC_BVH4_SORT_ANYHIT && V::kUnordered;
             int next;
@@ -867,7 +868,7 @@ __device__ __forceinline__ bool traverse_bvh4(const DScene<R>& S, const Ray<R>& 
 
 // the whole scene: unbounded prims, then the object BVH, then the triangle BVH (objects first, so
 // that the mesh walk starts with the tightest bound the cheap part can give)
-template <class R, class V> __device__ __forceinline__ void traverse_objects(const DScene<R>& S, const Ray<R>& ray, const RayInv& ri, R tlo, V& vis, int* stack) {
+template <class R, class V, bool FARW> __device__ __forceinline__ void traverse_objects(const DScene<R>& S, const Ray<R>& ray, const RayInv& ri, R tlo, V& vis, int* stack) {
     for (int i = 0; i < S.n_unbounded; i++)
         if (vis.prim(S.unbounded_prims[i])) return;
     if (S.n_flat_prims > 0) {
@@ -879,7 +880,7 @@ template <class R, class V> __device__ __forceinline__ void traverse_objects(con
         if (V::kFlatRootBox) {   // one box around all of them (the tree's own): the same conservative fp32 slab test as traverse_bvh's
             const float ix = ri.ix, iy = ri.iy, iz = ri.iz;
             const float* pb = S.obox;
-            const bool far_away = V::Cnt::kFar && fmaxf(fmaxf(fabsf((float)ray.o.x), fabsf((float)ray.o.y)), fabsf((float)ray.o.z)) > S.far_origin;
+            const bool far_away = FARW && fmaxf(fmaxf(fabsf((float)ray.o.x), fabsf((float)ray.o.y)), fabsf((float)ray.o.z)) > S.far_origin;
             if (!far_away) {     // (a ray from farther out is not culled here: its leaf tests, in R, decide)
                 const float ox = ri.ox, oy = ri.oy, oz = ri.oz;
                 float x0 = fmaf(pb[0], ix, ox), x1 = fmaf(pb[3], ix, ox);
@@ -897,10 +898,10 @@ template <class R, class V> __device__ __forceinline__ void traverse_objects(con
             if (vis.prim(S.bvh_prims[i])) return;
         return;
     }
-    if (S.n_bvh_nodes > 0) traverse_bvh<R, V>(S, ray, ri, tlo, vis, stack);
+    if (S.n_bvh_nodes > 0) traverse_bvh<R, V, FARW>(S, ray, ri, tlo, vis, stack);
 }
-template <class R, class V> __device__ __forceinline__ void traverse_tris(const DScene<R>& S, const Ray<R>& ray, const RayInv& ri, R tlo, V& vis, int* stack) {
-    if (S.n_tnodes > 0) traverse_bvh4<R, V>(S, ray, ri, tlo, vis, stack);
+template <class R, class V, bool FARW> __device__ __forceinline__ void traverse_tris(const DScene<R>& S, const Ray<R>& ray, const RayInv& ri, R tlo, V& vis, int* stack) {
+    if (S.n_tnodes > 0) traverse_bvh4<R, V, false, FARW>(S, ray, ri, tlo, vis, stack);
 }
 // Instances of meshes are prims of the object BVH: the visitors do not walk a mesh where they meet its box (the outer walk's
 // state would stay live through the inner one) but note the instance -- a byte each in one 64-bit word, in the order met,
@@ -911,10 +912,15 @@ struct PendingInstances {
     __device__ __forceinline__ void clear() { list = 0ull; n = 0; }
     __device__ __forceinline__ void add(int idx) { if (n < RTC_MAX_INSTANCES) { list |= (unsigned long long)(idx + 1) << (8 * n); n++; } }
 };
-template <class R, class V> __device__ __forceinline__ void traverse(const DScene<R>& S, const Ray<R>& ray, R tlo, V& vis, int* stack) {
+// FARW: whether THIS ray can start far outside the trees' boxes.  In a kernel variant for far cameras (Counters::kFar) that is the
+// camera ray alone -- every other ray starts on a surface of the scene (or far out on an unbounded plane, which the variants for
+// near cameras meet as well: the slab distances' relative slack grows with the origin) -- so only the camera ray's walks carry the
+// re-basing.  Instanced meshes are walked in their own object space, where any ray may start far out: their walks follow the
+// kernel's flag.
+template <class R, class V, bool FARW> __device__ __forceinline__ void traverse(const DScene<R>& S, const Ray<R>& ray, R tlo, V& vis, int* stack) {
     const RayInv ri = ray_inv(ray);
-    traverse_objects(S, ray, ri, tlo, vis, stack);
-    if (!vis.done()) traverse_tris(S, ray, ri, tlo, vis, stack);
+    traverse_objects<R, V, FARW>(S, ray, ri, tlo, vis, stack);
+    if (!vis.done()) traverse_tris<R, V, FARW>(S, ray, ri, tlo, vis, stack);
     if (V::Cnt::kInst) {
         unsigned long long list = vis.pending.list;
         vis.pending.clear();
@@ -925,7 +931,7 @@ template <class R, class V> __device__ __forceinline__ void traverse(const DScen
             const R* m = S.xform + 12 * (size_t)I[1];
             vis.oray.o = xpoint(m, ray.o); vis.oray.d = xvector(m, ray.d);
             vis.inst_leaf0 = I[2];
-            traverse_bvh4<R, V, true>(S, vis.oray, ray_inv(vis.oray), tlo, vis, stack, inst, I[0]);
+            traverse_bvh4<R, V, true, V::Cnt::kFar>(S, vis.oray, ray_inv(vis.oray), tlo, vis, stack, inst, I[0]);
         }
     }
 }
@@ -1410,7 +1416,7 @@ __device__ __forceinline__ bool is_shadowed(const DScene<R>& S, V3<R> light_posi
     Ray<R> r = {point, v * (R(1) / distance)};
     cnt.c[1]++;
     ShadowVisitor<R, CNT> vis(S, r, distance, cnt);
-    traverse(S, r, R(0), vis, stack);
+    traverse<R, ShadowVisitor<R, CNT>, false>(S, r, R(0), vis, stack);
     return vis.shadowed;
 }
 
@@ -1586,10 +1592,11 @@ __device__ __forceinline__ void container_result(const DScene<R>& S, int leaf, b
 
 // n1 / n2 of prepare_computations (renderer.py:224-242) via the order-free container pass
 template <class R, class CNT>
-__device__ __forceinline__ void container_n1n2(const DScene<R>& S, const Ray<R>& ray, R t, int leaf, int* stack, CNT& cnt, R& n1, R& n2) {
+__device__ __forceinline__ void container_n1n2(const DScene<R>& S, const Ray<R>& ray, bool primary, R t, int leaf, int* stack, CNT& cnt, R& n1, R& n2) {
     cnt.work(W_CONTAINER);
     ContainerVisitor<R, CNT> cv(S, ray, t, leaf, cnt);
-    traverse(S, ray, -inf_<R>(), cv, stack);
+    if (CNT::kFar && primary) traverse<R, ContainerVisitor<R, CNT>, true>(S, ray, -inf_<R>(), cv, stack);
+    else traverse<R, ContainerVisitor<R, CNT>, false>(S, ray, -inf_<R>(), cv, stack);
     container_result(S, leaf, cv.x_odd, cv.x_last, cv.y_leaf, cv.y_last, n1, n2);
 }
 
@@ -1651,10 +1658,11 @@ __device__ __forceinline__ bool needs_containers(double transparency, int remain
 // is called once for every ray that hits something; if it returns false the ray is given up here
 // (its caller will have it traced again some other way) and the light loop is skipped.
 template <class R, class CNT, class EMIT>
-__device__ __forceinline__ V3<R> shade_ray(const DScene<R>& S, const Ray<R>& ray, int remaining, uint32_t path, R shade_eps, R shade_eps_rel,
+__device__ __forceinline__ V3<R> shade_ray(const DScene<R>& S, const Ray<R>& ray, bool primary /* the camera ray */, int remaining, uint32_t path, R shade_eps, R shade_eps_rel,
                                            int* stack, CNT& cnt, uint64_t seed, uint32_t pixel, int& hit_leaf, EMIT& emit) {
     NearestVisitor<R, CNT> nv(S, ray, cnt);
-    traverse(S, ray, R(0), nv, stack);
+    if (CNT::kFar && primary) traverse<R, NearestVisitor<R, CNT>, true>(S, ray, R(0), nv, stack);
+    else traverse<R, NearestVisitor<R, CNT>, false>(S, ray, R(0), nv, stack);
     hit_leaf = nv.leaf;
     V3<R> surface = mk<R>(0, 0, 0);
     if (nv.leaf >= 0) {
@@ -1662,7 +1670,7 @@ __device__ __forceinline__ V3<R> shade_ray(const DScene<R>& S, const Ray<R>& ray
         HitCtx<R> c = make_ctx(S, ray, nv.best, nv.leaf, nv.u, nv.v, shade_eps, shade_eps_rel);
         if (S.mat_program[c.material] >= 0) cnt.work(W_PATTERN);
         R n1 = R(1), n2 = R(1);
-        if (S.refraction_matters && needs_containers(S.mat[10 * (size_t)c.material + 8], remaining)) container_n1n2(S, ray, c.t, c.leaf, stack, cnt, n1, n2);
+        if (S.refraction_matters && needs_containers(S.mat[10 * (size_t)c.material + 8], remaining)) container_n1n2(S, ray, primary, c.t, c.leaf, stack, cnt, n1, n2);
         Secondary<R> sec = secondary_rays(S, c, remaining, n1, n2);
         if (!emit(sec.refl, c.over_point, c.reflectv, sec.w_refl, sec.refr, c.under_point, sec.refr_dir, sec.w_refr)) return surface;
         V3<R> pcolor = surface_color<R, CNT::kCsg>(S, c.material, c.leaf, c.over_point);
@@ -1715,7 +1723,7 @@ __device__ __forceinline__ V3<R> trace_tree(const DScene<R>& S, Ray<R> ray, V3<R
     while (true) {
         int leaf;
         PushPending<R, CNT> push = {pending, np, weight, remaining, path, cnt};
-        V3<R> surface = shade_ray(S, ray, remaining, path, shade_eps, shade_eps_rel, stack, cnt, seed, pixel, leaf, push);
+        V3<R> surface = shade_ray(S, ray, first, remaining, path, shade_eps, shade_eps_rel, stack, cnt, seed, pixel, leaf, push);
         if (first) { first_leaf = leaf; first = false; }
         if (leaf >= 0) color = color + weight * surface;
         if (np == 0) break;
