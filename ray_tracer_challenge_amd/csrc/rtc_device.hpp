@@ -918,7 +918,11 @@ struct PendingInstances {
 // re-basing.  Instanced meshes are walked in their own object space, where any ray may start far out: their walks follow the
 // kernel's flag.
 template <class R, class V, bool FARW> __device__ __forceinline__ void traverse(const DScene<R>& S, const Ray<R>& ray, R tlo, V& vis, int* stack) {
-    const RayInv ri = ray_inv(ray);
+    // (a scene whose few objects are a flat list has no box test for this visitor's rays to make: the 56 M shadow rays of a
+    // shadow_glamour_shot frame need no reciprocals)
+    const bool boxes = S.n_tnodes > 0 || (S.n_flat_prims > 0 ? V::kFlatRootBox : S.n_bvh_nodes > 0);
+    RayInv ri = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    if (boxes) ri = ray_inv(ray);
     traverse_objects<R, V, FARW>(S, ray, ri, tlo, vis, stack);
     if (!vis.done()) traverse_tris<R, V, FARW>(S, ray, ri, tlo, vis, stack);
     if (V::Cnt::kInst) {
